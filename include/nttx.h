@@ -1,0 +1,115 @@
+/*
+ * nttx -- MI355X (gfx950) engine for the transform path of robertkiel/ntt.
+ *
+ * C ABI of libnttx.so.  The reference is a pure-Rust crate with no FFI of its
+ * own: the boundary it exposes is the `DFT<O>` trait (src/dft.rs:6-11) and the
+ * three table types that implement it.  Each entry point below names the
+ * reference interface whose body it replaces.  A Rust `extern "C"` block that
+ * binds exactly these symbols is shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes; no exceptions cross the boundary;
+ * every function returns an nttx_status (0 = ok) and leaves a message readable
+ * through nttx_last_error() on failure; the caller owns every buffer it passes;
+ * a plan is immutable after creation and may be used from several host threads.
+ * The reference reports errors by panicking; a Rust shim maps a non-zero status
+ * to panic!() to keep that contract.
+ */
+#ifndef NTTX_H
+#define NTTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nttx_plan nttx_plan;
+
+enum nttx_status {
+    NTTX_OK = 0,
+    NTTX_EINVAL = 1, /* argument outside the reference's own domain (would panic or be wrong there) */
+    NTTX_ENODEV = 2, /* no usable HIP device / bad device index */
+    NTTX_ENOMEM = 3, /* host or device allocation failed */
+    NTTX_EHIP = 4    /* a HIP runtime call failed */
+};
+
+enum nttx_kind {
+    NTTX_MONT64 = 0,    /* Table<u64> (src/dft/ntt.rs) and TableAVX2 (src/dft/ntt_avx2.rs): identical outputs */
+    NTTX_GOLDILOCKS = 1 /* TableGoldilock<u64> (src/dft/ntt_goldilock.rs) */
+};
+
+/*
+ * Creates a plan from tables the host computed exactly as the reference does.
+ *
+ * Replaces the table-owning half of Table::from_prime_and_root (ntt.rs:90-120),
+ * TableAVX2::from_prime_and_root (ntt_avx2.rs:74-105) and TableGoldilock::new
+ * (ntt_goldilock.rs:48-58): the struct keeps q/psi and calls this with
+ *   NTTX_MONT64:     k = MontgomeryTransformer.k (utils.rs:130), n_inv = n_inv_montgomery
+ *                    (ntt.rs:13), psi_bo / psi_inv_bo = powers_psi_bo / powers_psi_inv_bo
+ *                    (ntt.rs:17-20), all in Montgomery form as with_precomputes (ntt.rs:239-261)
+ *                    leaves them;
+ *   NTTX_GOLDILOCKS: q must be 0xffffffff00000001, k is ignored, n_inv and both tables
+ *                    are plain residues (ntt_goldilock.rs:12-14, 192-214).
+ * n must be a power of two with even log2 (utils.rs:14-17 makes every odd log2 n panic in
+ * the reference), 4 <= n <= 2^32.  For NTTX_MONT64 q must be odd (utils.rs:144-146) and k*q
+ * must be 1 mod 2^64 (utils.rs:148-152 yields a wrong k, hence wrong transforms, otherwise).
+ * Tables (n entries each) are copied to every listed device; devices == NULL / n_devices == 0
+ * means device 0 only.
+ */
+int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_inv,
+                     const uint64_t *psi_bo, const uint64_t *psi_inv_bo,
+                     const int *devices, int n_devices, nttx_plan **out);
+
+/*
+ * Same, with the host precompute done inside the library from (q, psi, n):
+ * a C++ restatement of MontgomeryTransformer::from_modulus (utils.rs:141-162),
+ * Table::from_prime_and_root + with_precomputes (ntt.rs:90-120, 239-261) and
+ * TableGoldilock::with_precomputes (ntt_goldilock.rs:192-214).  For callers with no
+ * host-side table code (tests, the benchmark, C and Python users).
+ */
+int nttx_plan_create_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n,
+                               const int *devices, int n_devices, nttx_plan **out);
+
+void nttx_plan_destroy(nttx_plan *plan);
+
+/* Read-back of what a plan holds (for parity tests against the reference's pub fields
+ * Table::powers_psi_bo / powers_psi_inv_bo, ntt.rs:17-20).  Any out pointer may be NULL. */
+int nttx_plan_info(const nttx_plan *plan, int *kind, uint64_t *q, uint64_t *k, uint64_t *n,
+                   uint64_t *n_inv, int *n_devices);
+int nttx_plan_tables(const nttx_plan *plan, uint64_t *psi_bo_out, uint64_t *psi_inv_bo_out);
+
+/*
+ * In-place transforms of `batch` independent length-n vectors stored back to back in HOST
+ * memory (batch*n u64, little endian).  batch == 1 is DFT::forward_inplace / backward_inplace
+ * (dft.rs:7,9) for Table<u64> (ntt.rs:27-29, 41-43), TableAVX2 (ntt_avx2.rs:30-32, 44-46; pass
+ * the i64 slice reinterpreted) and TableGoldilock<u64> (ntt_goldilock.rs:21-23, 35-37); the
+ * *_lazy trait methods (dft.rs:8,10) bind the same symbols because the reference's LAZY flag is
+ * never read (ntt.rs:122, 178).  batch > 1 has no counterpart in the reference (it loops).
+ * Copies to the plan's devices, splits the batch evenly across them, transforms, copies back.
+ * Forward: natural order in, bit-reversed order out.  Backward: bit-reversed in, natural out,
+ * scaled by n^-1.
+ */
+int nttx_forward_host(const nttx_plan *plan, uint64_t *data, size_t batch);
+int nttx_backward_host(const nttx_plan *plan, uint64_t *data, size_t batch);
+
+/*
+ * Same transforms on data already resident in the memory of `device` (one of the plan's
+ * devices), enqueued on `hip_stream` (a hipStream_t, NULL = default stream) without any
+ * host synchronisation.  This is the measured path; no counterpart in the reference.
+ */
+int nttx_forward_device(const nttx_plan *plan, int device, void *dptr, size_t batch, void *hip_stream);
+int nttx_backward_device(const nttx_plan *plan, int device, void *dptr, size_t batch, void *hip_stream);
+
+/* Name and average duration bookkeeping for the benchmark: number of kernel launches one
+ * forward (dir = 0) or backward (dir = 1) call issues for this plan and batch. */
+int nttx_launches_per_call(const nttx_plan *plan, size_t batch, int dir);
+
+int nttx_device_count(void);
+const char *nttx_last_error(void); /* thread-local, never NULL */
+const char *nttx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,300 @@
+// Transform kernels for gfx950.
+//
+// One launch ("pass") applies K = K1 + K2 consecutive butterfly stages to every element of
+// the batch.  Before a pass that starts after s0 stages the data of one transform is split
+// into 2^s0 independent blocks of B = n / 2^s0 elements; inside a block the K stages act on
+// 2^K elements at stride T = B / 2^K, with twiddles that depend only on the block and on the
+// position inside that 2^K-point sub-transform (reference index structure: ntt.rs:129-171 for
+// the forward Cooley-Tukey order, ntt.rs:185-229 for the backward Gentleman-Sande order).
+//
+// A workgroup of 256 threads owns a tile of 4096 elements = 4096 / 2^K sub-transforms, and
+// every thread keeps 16 elements in registers.  The K stages run as two register rounds
+// (K1 stages, exchange through LDS, K2 stages) so a tile crosses HBM once per pass.
+//   STRIDED tile: 2^K rows x (4096 / 2^K) adjacent columns, rows T elements apart; every
+//                 global access is a run of >= 128 contiguous bytes.  Used while T > 1.
+//   CONTIG  tile: 4096 contiguous elements (T = 1, the pass that holds the stride-1 stage);
+//                 moved between HBM and LDS with 16-byte-per-lane accesses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "arith.hpp"
+
+namespace nttx {
+
+constexpr int TILE_LOG = 12;
+constexpr int TILE = 1 << TILE_LOG;      // elements per workgroup
+constexpr int THREADS = 256;             // 4 waves
+constexpr int REGS = TILE / THREADS;     // 16 elements per thread
+constexpr int LDS_ELEMS = TILE + TILE / 16;
+
+enum : uint32_t {
+    PASS_CONDITION_INPUT = 1u, // first pass of a transform: map arbitrary u64 input to residues
+    PASS_SCALE = 2u            // pass holding stage 1 of the inverse: fold the n^-1 factor in
+};
+
+struct PassParams {
+    uint64_t* data;
+    const uint64_t* tw;       // psi_bo (forward) or psi_inv_bo (backward), n entries
+    uint64_t nblocks_total;   // batch << s0
+    uint32_t logB;            // log2 of the block size n >> s0
+    uint32_t s0;              // stages that precede this pass in forward order
+    uint32_t flags;
+};
+
+// K butterfly stages on 2^K registers.  Register i holds sub-transform element i (stride
+// handled by the caller); stage u = 1..K pairs i with i + 2^(K-u) and uses twiddle
+// tw[(P << (u-1)) + (i >> (K-u+1))], which is the reference's powers_psi_bo[m + i] with
+// m = P << (u-1) (ntt.rs:139-147 forward, :196-221 backward).
+template <class A, int K, bool FWD>
+__device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const uint64_t* __restrict__ tw, uint64_t P,
+                                      const typename A::Ctx& c, bool scale)
+{
+    constexpr int M = 1 << K;
+    uint64_t w[M];
+#pragma unroll
+    for (int u = 1; u <= K; u++) {
+#pragma unroll
+        for (int b = 0; b < (1 << (u - 1)); b++)
+            w[(1 << (u - 1)) + b] = tw[(P << (u - 1)) + b];
+    }
+    if (FWD) {
+#pragma unroll
+        for (int u = 1; u <= K; u++) {
+            const int half = M >> u;
+#pragma unroll
+            for (int b = 0; b < (1 << (u - 1)); b++) {
+                const uint64_t s = w[(1 << (u - 1)) + b];
+#pragma unroll
+                for (int i = 0; i < half; i++) {
+                    const int lo = b * 2 * half + i, hi = lo + half;
+                    const uint64_t U = x[lo];
+                    const uint64_t V = A::mul(x[hi], s, c);
+                    x[lo] = A::add(U, V, c);
+                    x[hi] = A::sub_ct(U, V, c);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = K; u >= 1; u--) {
+            const int half = M >> u;
+            if (u == 1 && scale) {
+                // last stage of the inverse: (U+V)*n^-1 and (U-V)*(S*n^-1)  (ntt.rs:231-235)
+                const uint64_t f = A::scale_factor(c);
+                const uint64_t sf = A::mul(w[1], f, c);
+#pragma unroll
+                for (int i = 0; i < half; i++) {
+                    const uint64_t U = x[i], V = x[i + half];
+                    x[i] = A::mul(A::add(U, V, c), f, c);
+                    x[i + half] = A::mul(A::sub_gs(U, V, c), sf, c);
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < (1 << (u - 1)); b++) {
+                    const uint64_t s = w[(1 << (u - 1)) + b];
+#pragma unroll
+                    for (int i = 0; i < half; i++) {
+                        const int lo = b * 2 * half + i, hi = lo + half;
+                        const uint64_t U = x[lo], V = x[hi];
+                        x[lo] = A::add(U, V, c);
+                        x[hi] = A::mul(A::sub_gs(U, V, c), s, c);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <bool CONTIG, int K>
+__device__ __forceinline__ uint32_t lds_addr(uint32_t sigma, uint32_t r)
+{
+    if (CONTIG) {
+        const uint32_t f = (sigma << K) + r;
+        return f + (f >> 4);
+    } else {
+        const uint32_t f = (r << (TILE_LOG - K)) + sigma;
+        return f + ((f >> 8) << 4);
+    }
+}
+
+// Geometry of one tile, shared by all rounds of a pass.
+template <int K>
+struct TileGeom {
+    uint32_t logB, logT, logCw, lognblk, logtpb, s0;
+    uint64_t tile, nblocks_total;
+
+    __device__ __forceinline__ TileGeom(const PassParams& p, uint64_t tile_)
+    {
+        constexpr uint32_t logS = TILE_LOG - K;
+        logB = p.logB;
+        s0 = p.s0;
+        logT = logB - K;
+        logCw = logT < logS ? logT : logS;
+        lognblk = logS - logCw;
+        logtpb = logT - logCw;
+        tile = tile_;
+        nblocks_total = p.nblocks_total;
+    }
+    __device__ __forceinline__ uint64_t block_of(uint32_t sigma) const
+    {
+        return ((tile >> logtpb) << lognblk) + (sigma >> logCw);
+    }
+    __device__ __forceinline__ uint64_t column_of(uint32_t sigma) const
+    {
+        return ((tile & ((1ull << logtpb) - 1)) << logCw) + (sigma & ((1u << logCw) - 1));
+    }
+    // index of element r of sub-transform sigma in the batch array
+    __device__ __forceinline__ uint64_t gidx(uint32_t sigma, uint32_t r) const
+    {
+        return (block_of(sigma) << logB) + ((uint64_t)r << logT) + column_of(sigma);
+    }
+    __device__ __forceinline__ bool valid(uint32_t sigma) const { return block_of(sigma) < nblocks_total; }
+    // twiddle base of the block: 2^s0 + (block index inside its transform)
+    __device__ __forceinline__ uint64_t twiddle_base(uint32_t sigma) const
+    {
+        return (1ull << s0) + (block_of(sigma) & ((1ull << s0) - 1));
+    }
+};
+
+// One register round of a pass.  ROUND_A covers the K1 stages with the larger strides
+// (elements rlow + (i << K2)), round B the K2 stages with the smaller ones (elements
+// (rhigh << K2) + i).  SRC_G / DST_G: read from / write to HBM directly instead of LDS.
+template <class A, bool FWD, bool CONTIG, int K1, int K2, bool ROUND_A, bool SRC_G, bool DST_G>
+__device__ __forceinline__ void do_round(const PassParams& p, const TileGeom<K1 + K2>& g, const typename A::Ctx& c,
+                                         uint64_t* lds)
+{
+    constexpr int K = K1 + K2;
+    constexpr int KR = ROUND_A ? K1 : K2;       // stages in this round
+    constexpr int KO = ROUND_A ? K2 : K1;       // stages in the other round
+    constexpr int M = 1 << KR;
+    constexpr int GROUPS = REGS / M;
+    constexpr uint32_t logS = TILE_LOG - K;
+    const bool scale = ROUND_A && (p.flags & PASS_SCALE);
+    const bool cond = SRC_G && (p.flags & PASS_CONDITION_INPUT);
+
+#pragma unroll
+    for (int gamma = 0; gamma < GROUPS; gamma++) {
+        const uint32_t slot = gamma * THREADS + threadIdx.x;
+        uint32_t sigma, rpart;
+        if (CONTIG) {
+            rpart = slot & ((1u << KO) - 1);
+            sigma = slot >> KO;
+        } else {
+            sigma = slot & ((1u << logS) - 1);
+            rpart = slot >> logS;
+        }
+        // element i of this group is sub-transform element r(i)
+        const uint32_t r0 = ROUND_A ? rpart : (rpart << K2);
+        const uint32_t rstep_log = ROUND_A ? K2 : 0;
+        const bool ok = g.valid(sigma);
+        const uint64_t P = ROUND_A ? g.twiddle_base(sigma) : ((g.twiddle_base(sigma) << K1) + rpart);
+
+        uint64_t x[M];
+        if (SRC_G) {
+            const uint64_t base = g.gidx(sigma, r0);
+            const uint64_t step = 1ull << (g.logT + rstep_log);
+#pragma unroll
+            for (int i = 0; i < M; i++)
+                x[i] = ok ? p.data[base + i * step] : 0;
+            if (cond) {
+#pragma unroll
+                for (int i = 0; i < M; i++)
+                    x[i] = A::condition_input(x[i], c);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < M; i++)
+                x[i] = lds[lds_addr<CONTIG, K>(sigma, r0 + (i << rstep_log))];
+        }
+
+        radix<A, KR, FWD>(x, p.tw, ok ? P : 1, c, scale);
+
+        if (DST_G) {
+            if (ok) {
+                const uint64_t base = g.gidx(sigma, r0);
+                const uint64_t step = 1ull << (g.logT + rstep_log);
+#pragma unroll
+                for (int i = 0; i < M; i++)
+                    p.data[base + i * step] = x[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < M; i++)
+                lds[lds_addr<CONTIG, K>(sigma, r0 + (i << rstep_log))] = x[i];
+        }
+    }
+}
+
+// Copies a CONTIG tile between HBM and LDS, 16 bytes per lane.
+template <class A, int K, bool TO_LDS>
+__device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<K>& g, const typename A::Ctx& c,
+                                            uint64_t* lds)
+{
+    const uint64_t total = p.nblocks_total << p.logB;
+    const uint64_t base = g.tile << TILE_LOG;
+    const bool cond = TO_LDS && (p.flags & PASS_CONDITION_INPUT);
+#pragma unroll
+    for (int i = 0; i < REGS / 2; i++) {
+        const uint32_t f = 2 * (i * THREADS + threadIdx.x);
+        const uint32_t a0 = f + (f >> 4); // f is even, so f and f+1 share a padding group
+        if (base + f < total) {           // total is a multiple of 4 (n >= 4), f even
+            if (TO_LDS) {
+                ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p.data + base + f);
+                if (cond) {
+                    v.x = A::condition_input(v.x, c);
+                    v.y = A::condition_input(v.y, c);
+                }
+                lds[a0] = v.x;
+                lds[a0 + 1] = v.y;
+            } else {
+                ulonglong2 v;
+                v.x = lds[a0];
+                v.y = lds[a0 + 1];
+                *reinterpret_cast<ulonglong2*>(p.data + base + f) = v;
+            }
+        }
+    }
+}
+
+template <class A, bool FWD, bool CONTIG, int K1, int K2>
+__global__ __launch_bounds__(THREADS) void pass_kernel(PassParams p, typename A::Ctx c)
+{
+    constexpr int K = K1 + K2;
+    __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
+    const TileGeom<K> g(p, blockIdx.x);
+
+    if constexpr (CONTIG) {
+        copy_contig<A, K, true>(p, g, c, lds);
+        __syncthreads();
+        if constexpr (FWD) {
+            do_round<A, FWD, CONTIG, K1, K2, true, false, false>(p, g, c, lds);
+            if constexpr (K2 > 0) {
+                __syncthreads();
+                do_round<A, FWD, CONTIG, K1, K2, false, false, false>(p, g, c, lds);
+            }
+        } else {
+            if constexpr (K2 > 0) {
+                do_round<A, FWD, CONTIG, K1, K2, false, false, false>(p, g, c, lds);
+                __syncthreads();
+            }
+            do_round<A, FWD, CONTIG, K1, K2, true, false, false>(p, g, c, lds);
+        }
+        __syncthreads();
+        copy_contig<A, K, false>(p, g, c, lds);
+    } else {
+        if constexpr (K2 == 0) {
+            do_round<A, FWD, CONTIG, K1, K2, true, true, true>(p, g, c, lds);
+        } else if constexpr (FWD) {
+            do_round<A, FWD, CONTIG, K1, K2, true, true, false>(p, g, c, lds);
+            __syncthreads();
+            do_round<A, FWD, CONTIG, K1, K2, false, false, true>(p, g, c, lds);
+        } else {
+            do_round<A, FWD, CONTIG, K1, K2, false, true, false>(p, g, c, lds);
+            __syncthreads();
+            do_round<A, FWD, CONTIG, K1, K2, true, false, true>(p, g, c, lds);
+        }
+    }
+}
+
+} // namespace nttx

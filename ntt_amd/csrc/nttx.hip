@@ -1,0 +1,452 @@
+// libnttx: plans, pass scheduling and the C ABI declared in include/nttx.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/nttx.h"
+#include "../host/tables.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? NTTX_ENOMEM : NTTX_EHIP,                       \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+struct PassDesc {
+    int k1, k2;
+    bool contig;
+    uint32_t s0;
+};
+
+} // namespace
+
+struct nttx_plan {
+    int kind = 0;
+    uint64_t q = 0, k = 0, n = 0, n_inv = 0;
+    uint32_t logn = 0;
+    bool wide = false; // q >= 2^63: carry-aware additions
+    nttx::MontCtx mctx{};
+    nttx::GoldilocksCtx gctx{};
+    std::vector<uint64_t> h_fwd, h_inv;
+    std::vector<int> devices;
+    std::vector<uint64_t*> d_fwd, d_inv; // per device
+    std::vector<PassDesc> passes;        // forward order
+};
+
+namespace {
+
+using namespace nttx;
+
+// Splits log2(n) stages into passes: an optional first pass with log2(n) mod 8 stages,
+// then passes of 8 stages; the last one holds the stride-1 stage (CONTIG).
+std::vector<PassDesc> make_passes(uint32_t logn)
+{
+    auto split = [](int k, int& k1, int& k2) {
+        k1 = k >= 4 ? 4 : k;
+        k2 = k - k1;
+    };
+    std::vector<PassDesc> out;
+    if (logn <= 8) {
+        PassDesc d{0, 0, true, 0};
+        split((int)logn, d.k1, d.k2);
+        out.push_back(d);
+        return out;
+    }
+    uint32_t s0 = 0;
+    const int r = (int)(logn % 8);
+    if (r) {
+        PassDesc d{0, 0, false, 0};
+        split(r, d.k1, d.k2);
+        out.push_back(d);
+        s0 += (uint32_t)r;
+    }
+    while (s0 < logn) {
+        PassDesc d{4, 4, s0 + 8 == logn, s0};
+        out.push_back(d);
+        s0 += 8;
+    }
+    return out;
+}
+
+template <class A, bool FWD, bool CONTIG, int K1, int K2>
+hipError_t launch_one(const PassParams& p, const typename A::Ctx& c, unsigned grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((pass_kernel<A, FWD, CONTIG, K1, K2>), dim3(grid), dim3(THREADS), 0, s, p, c);
+    return hipGetLastError();
+}
+
+template <class A, bool FWD>
+hipError_t launch_shape(const PassDesc& d, const PassParams& p, const typename A::Ctx& c, unsigned grid,
+                        hipStream_t s)
+{
+    const int key = (d.contig ? 100 : 0) + d.k1 * 10 + d.k2;
+    switch (key) {
+    case 120: return launch_one<A, FWD, true, 2, 0>(p, c, grid, s);
+    case 140: return launch_one<A, FWD, true, 4, 0>(p, c, grid, s);
+    case 142: return launch_one<A, FWD, true, 4, 2>(p, c, grid, s);
+    case 144: return launch_one<A, FWD, true, 4, 4>(p, c, grid, s);
+    case 20: return launch_one<A, FWD, false, 2, 0>(p, c, grid, s);
+    case 40: return launch_one<A, FWD, false, 4, 0>(p, c, grid, s);
+    case 42: return launch_one<A, FWD, false, 4, 2>(p, c, grid, s);
+    case 44: return launch_one<A, FWD, false, 4, 4>(p, c, grid, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <class A>
+hipError_t launch_dir(bool fwd, const PassDesc& d, const PassParams& p, const typename A::Ctx& c, unsigned grid,
+                      hipStream_t s)
+{
+    return fwd ? launch_shape<A, true>(d, p, c, grid, s) : launch_shape<A, false>(d, p, c, grid, s);
+}
+
+int device_slot(const nttx_plan* plan, int device)
+{
+    for (size_t i = 0; i < plan->devices.size(); i++)
+        if (plan->devices[i] == device)
+            return (int)i;
+    return -1;
+}
+
+// Enqueues one transform of `batch` vectors at dptr on the current device.
+int enqueue(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream)
+{
+    if (batch == 0)
+        return NTTX_OK;
+    const uint64_t total = (uint64_t)batch << plan->logn;
+    if ((total >> plan->logn) != batch || total > (1ull << 40))
+        return fail(NTTX_EINVAL, "batch * n is too large");
+    const uint64_t tiles = (total + TILE - 1) / TILE;
+    if (tiles > 0x7fffffffull)
+        return fail(NTTX_EINVAL, "batch * n is too large for one launch");
+
+    const size_t np = plan->passes.size();
+    for (size_t i = 0; i < np; i++) {
+        const PassDesc& d = plan->passes[fwd ? i : np - 1 - i];
+        PassParams p;
+        p.data = dptr;
+        p.tw = fwd ? plan->d_fwd[slot] : plan->d_inv[slot];
+        p.nblocks_total = (uint64_t)batch << d.s0;
+        p.logB = plan->logn - d.s0;
+        p.s0 = d.s0;
+        p.flags = 0;
+        if (i == 0)
+            p.flags |= PASS_CONDITION_INPUT;
+        if (!fwd && d.s0 == 0)
+            p.flags |= PASS_SCALE;
+        hipError_t e;
+        if (plan->kind == NTTX_GOLDILOCKS)
+            e = launch_dir<Goldilocks>(fwd, d, p, plan->gctx, (unsigned)tiles, stream);
+        else if (plan->wide)
+            e = launch_dir<Mont<true>>(fwd, d, p, plan->mctx, (unsigned)tiles, stream);
+        else
+            e = launch_dir<Mont<false>>(fwd, d, p, plan->mctx, (unsigned)tiles, stream);
+        if (e != hipSuccess)
+            return fail(NTTX_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    }
+    return NTTX_OK;
+}
+
+int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd)
+{
+    if (!plan)
+        return fail(NTTX_EINVAL, "plan is NULL");
+    if (batch == 0)
+        return NTTX_OK;
+    if (!data)
+        return fail(NTTX_EINVAL, "data is NULL");
+    const size_t ndev = plan->devices.size();
+    const size_t per = (batch + ndev - 1) / ndev;
+    struct Work {
+        uint64_t* d = nullptr;
+        hipStream_t s = nullptr;
+        size_t first = 0, count = 0;
+    };
+    std::vector<Work> work(ndev);
+    int rc = NTTX_OK;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+
+    auto body = [&]() -> int {
+        for (size_t i = 0; i < ndev; i++) {
+            Work& w = work[i];
+            w.first = i * per;
+            if (w.first >= batch)
+                break;
+            w.count = std::min(per, batch - w.first);
+            const size_t bytes = (w.count << plan->logn) * sizeof(uint64_t);
+            HIP_TRY(hipSetDevice(plan->devices[i]));
+            HIP_TRY(hipStreamCreateWithFlags(&w.s, hipStreamNonBlocking));
+            HIP_TRY(hipMalloc(&w.d, bytes));
+            HIP_TRY(hipMemcpyAsync(w.d, data + (w.first << plan->logn), bytes, hipMemcpyHostToDevice, w.s));
+            int r = enqueue(plan, (int)i, w.d, w.count, fwd, w.s);
+            if (r != NTTX_OK)
+                return r;
+            HIP_TRY(hipMemcpyAsync(data + (w.first << plan->logn), w.d, bytes, hipMemcpyDeviceToHost, w.s));
+        }
+        for (size_t i = 0; i < ndev; i++) {
+            if (!work[i].s)
+                continue;
+            HIP_TRY(hipSetDevice(plan->devices[i]));
+            HIP_TRY(hipStreamSynchronize(work[i].s));
+        }
+        return NTTX_OK;
+    };
+    rc = body();
+    for (size_t i = 0; i < ndev; i++) {
+        if (!work[i].s && !work[i].d)
+            continue;
+        (void)hipSetDevice(plan->devices[i]);
+        if (work[i].s) {
+            (void)hipStreamSynchronize(work[i].s);
+            (void)hipStreamDestroy(work[i].s);
+        }
+        if (work[i].d)
+            (void)hipFree(work[i].d);
+    }
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+int run_device(const nttx_plan* plan, int device, void* dptr, size_t batch, void* stream, bool fwd)
+{
+    if (!plan)
+        return fail(NTTX_EINVAL, "plan is NULL");
+    const int slot = device_slot(plan, device);
+    if (slot < 0)
+        return fail(NTTX_ENODEV, "device is not one of the plan's devices");
+    if (batch == 0)
+        return NTTX_OK;
+    if (!dptr || (reinterpret_cast<uintptr_t>(dptr) & 15))
+        return fail(NTTX_EINVAL, "device pointer must be non-NULL and 16-byte aligned");
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != device)
+        HIP_TRY(hipSetDevice(device));
+    int rc = enqueue(plan, slot, static_cast<uint64_t*>(dptr), batch, fwd, static_cast<hipStream_t>(stream));
+    if (cur != device && cur >= 0)
+        (void)hipSetDevice(cur);
+    return rc;
+}
+
+int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(NTTX_ENODEV, "no HIP device available");
+    if (devices == nullptr || n_devices <= 0)
+        plan->devices = {0};
+    else
+        plan->devices.assign(devices, devices + n_devices);
+    for (size_t i = 0; i < plan->devices.size(); i++) {
+        if (plan->devices[i] < 0 || plan->devices[i] >= count)
+            return fail(NTTX_ENODEV, "device index out of range");
+        for (size_t j = 0; j < i; j++)
+            if (plan->devices[j] == plan->devices[i])
+                return fail(NTTX_EINVAL, "device listed twice");
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    const size_t bytes = plan->n * sizeof(uint64_t);
+    plan->d_fwd.assign(plan->devices.size(), nullptr);
+    plan->d_inv.assign(plan->devices.size(), nullptr);
+    for (size_t i = 0; i < plan->devices.size(); i++) {
+        HIP_TRY(hipSetDevice(plan->devices[i]));
+        HIP_TRY(hipMalloc(&plan->d_fwd[i], bytes));
+        HIP_TRY(hipMalloc(&plan->d_inv[i], bytes));
+        HIP_TRY(hipMemcpy(plan->d_fwd[i], plan->h_fwd.data(), bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(plan->d_inv[i], plan->h_inv.data(), bytes, hipMemcpyHostToDevice));
+    }
+    (void)hipSetDevice(prev);
+    return NTTX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_inv, const uint64_t* psi_bo,
+                     const uint64_t* psi_inv_bo, const int* devices, int n_devices, nttx_plan** out)
+{
+    if (!out)
+        return fail(NTTX_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (kind != NTTX_MONT64 && kind != NTTX_GOLDILOCKS)
+        return fail(NTTX_EINVAL, "unknown kind");
+    if (!psi_bo || !psi_inv_bo)
+        return fail(NTTX_EINVAL, "twiddle tables are NULL");
+    if (n < 4 || n > (1ull << 32) || (n & (n - 1)) != 0)
+        return fail(NTTX_EINVAL, "n must be a power of two in [4, 2^32]");
+    const uint32_t logn = ntt::host::ilog2(n);
+    if (logn % 2 != 0)
+        return fail(NTTX_EINVAL, "log2(n) must be even: the reference's bit_reverse (utils.rs:14-17) "
+                                 "indexes out of bounds for odd log2(n)");
+    if (kind == NTTX_MONT64) {
+        if ((q & 1) == 0 || q < 3)
+            return fail(NTTX_EINVAL, "modulus is not coprime to helper modulus R=2^64");
+        if (k * q != 1)
+            return fail(NTTX_EINVAL, "k * q != 1 mod 2^64: the reference derives a wrong k for this modulus "
+                                     "(utils.rs:148-152)");
+    } else if (q != nttx::Goldilocks::Q) {
+        return fail(NTTX_EINVAL, "NTTX_GOLDILOCKS requires q = 0xffffffff00000001");
+    }
+    if (n_inv >= q)
+        return fail(NTTX_EINVAL, "n_inv is not a residue");
+    for (uint64_t i = 0; i < n; i++)
+        if (psi_bo[i] >= q || psi_inv_bo[i] >= q)
+            return fail(NTTX_EINVAL, "twiddle table entry is not a residue");
+
+    nttx_plan* plan = new (std::nothrow) nttx_plan;
+    if (!plan)
+        return fail(NTTX_ENOMEM, "out of host memory");
+    plan->kind = kind;
+    plan->q = q;
+    plan->k = k;
+    plan->n = n;
+    plan->n_inv = n_inv;
+    plan->logn = logn;
+    plan->wide = (q >> 63) != 0;
+    plan->mctx = nttx::MontCtx{q, k, (uint64_t)((((unsigned __int128)1) << 64) % q), n_inv};
+    plan->gctx = nttx::GoldilocksCtx{n_inv};
+    try {
+        plan->h_fwd.assign(psi_bo, psi_bo + n);
+        plan->h_inv.assign(psi_inv_bo, psi_inv_bo + n);
+    } catch (const std::bad_alloc&) {
+        delete plan;
+        return fail(NTTX_ENOMEM, "out of host memory");
+    }
+    plan->passes = make_passes(logn);
+    int rc = finish_plan(plan, devices, n_devices);
+    if (rc != NTTX_OK) {
+        std::string keep = g_err;
+        nttx_plan_destroy(plan);
+        g_err = keep;
+        return rc;
+    }
+    *out = plan;
+    return NTTX_OK;
+}
+
+int nttx_plan_create_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n, const int* devices, int n_devices,
+                               nttx_plan** out)
+{
+    if (!out)
+        return fail(NTTX_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n < 4 || n > (1ull << 32) || (n & (n - 1)) != 0)
+        return fail(NTTX_EINVAL, "n must be a power of two in [4, 2^32]");
+    try {
+        if (kind == NTTX_MONT64) {
+            if (q < 3 || psi == 0 || psi >= q)
+                return fail(NTTX_EINVAL, "need 0 < psi < q");
+            auto t = ntt::host::build_montgomery_tables(q, psi, n);
+            return nttx_plan_create(kind, q, t.montgomery.k, n, t.n_inv_montgomery, t.powers_psi_bo.data(),
+                                    t.powers_psi_inv_bo.data(), devices, n_devices, out);
+        } else if (kind == NTTX_GOLDILOCKS) {
+            if (q != nttx::Goldilocks::Q)
+                return fail(NTTX_EINVAL, "NTTX_GOLDILOCKS requires q = 0xffffffff00000001");
+            if (psi == 0 || psi >= q)
+                return fail(NTTX_EINVAL, "need 0 < psi < q");
+            auto t = ntt::host::build_goldilocks_tables(psi, n);
+            return nttx_plan_create(kind, q, 0, n, t.n_inv, t.powers_psi_bo.data(), t.powers_psi_inv_bo.data(),
+                                    devices, n_devices, out);
+        }
+    } catch (const ntt::Panic& p) {
+        return fail(NTTX_EINVAL, p.what());
+    } catch (const std::bad_alloc&) {
+        return fail(NTTX_ENOMEM, "out of host memory");
+    }
+    return fail(NTTX_EINVAL, "unknown kind");
+}
+
+void nttx_plan_destroy(nttx_plan* plan)
+{
+    if (!plan)
+        return;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (size_t i = 0; i < plan->devices.size(); i++) {
+        (void)hipSetDevice(plan->devices[i]);
+        if (i < plan->d_fwd.size() && plan->d_fwd[i])
+            (void)hipFree(plan->d_fwd[i]);
+        if (i < plan->d_inv.size() && plan->d_inv[i])
+            (void)hipFree(plan->d_inv[i]);
+    }
+    (void)hipSetDevice(prev);
+    delete plan;
+}
+
+int nttx_plan_info(const nttx_plan* plan, int* kind, uint64_t* q, uint64_t* k, uint64_t* n, uint64_t* n_inv,
+                   int* n_devices)
+{
+    if (!plan)
+        return fail(NTTX_EINVAL, "plan is NULL");
+    if (kind) *kind = plan->kind;
+    if (q) *q = plan->q;
+    if (k) *k = plan->k;
+    if (n) *n = plan->n;
+    if (n_inv) *n_inv = plan->n_inv;
+    if (n_devices) *n_devices = (int)plan->devices.size();
+    return NTTX_OK;
+}
+
+int nttx_plan_tables(const nttx_plan* plan, uint64_t* psi_bo_out, uint64_t* psi_inv_bo_out)
+{
+    if (!plan)
+        return fail(NTTX_EINVAL, "plan is NULL");
+    if (psi_bo_out)
+        std::memcpy(psi_bo_out, plan->h_fwd.data(), plan->n * sizeof(uint64_t));
+    if (psi_inv_bo_out)
+        std::memcpy(psi_inv_bo_out, plan->h_inv.data(), plan->n * sizeof(uint64_t));
+    return NTTX_OK;
+}
+
+int nttx_forward_host(const nttx_plan* plan, uint64_t* data, size_t batch) { return run_host(plan, data, batch, true); }
+int nttx_backward_host(const nttx_plan* plan, uint64_t* data, size_t batch) { return run_host(plan, data, batch, false); }
+
+int nttx_forward_device(const nttx_plan* plan, int device, void* dptr, size_t batch, void* hip_stream)
+{
+    return run_device(plan, device, dptr, batch, hip_stream, true);
+}
+int nttx_backward_device(const nttx_plan* plan, int device, void* dptr, size_t batch, void* hip_stream)
+{
+    return run_device(plan, device, dptr, batch, hip_stream, false);
+}
+
+int nttx_launches_per_call(const nttx_plan* plan, size_t batch, int dir)
+{
+    (void)dir;
+    if (!plan || batch == 0)
+        return 0;
+    return (int)plan->passes.size();
+}
+
+int nttx_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess)
+        return 0;
+    return count;
+}
+
+const char* nttx_last_error(void) { return g_err.c_str(); }
+const char* nttx_version(void) { return "nttx 0.1 (gfx950)"; }
+
+} // extern "C"

@@ -1,0 +1,70 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/nttx.h
+declares, and rejects bad arguments without touching a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ntt_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "nttx.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(nttx_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(_lib.lib, name)
+
+
+def test_argument_validation_needs_no_gpu():
+    from ntt_amd import _lib
+
+    lib = _lib.lib
+    plan = C.c_void_p()
+    tab = (C.c_uint64 * 16)(*([1] * 16))
+    q61, k61 = 0x1FFFFFFFFFE00001, 6917533425689690113
+    # odd log2 n (utils.rs:14-17 makes the reference panic)
+    assert lib.nttx_plan_create(0, q61, k61, 8, 1, tab, tab, None, 0, C.byref(plan)) == _lib.NTTX_EINVAL
+    assert "even" in _lib.last_error()
+    # even modulus (utils.rs:144-146)
+    assert lib.nttx_plan_create(0, 1 << 20, 1, 16, 1, tab, tab, None, 0, C.byref(plan)) == _lib.NTTX_EINVAL
+    # k that is not q^-1 mod 2^64 (utils.rs:148-152 for e.g. 7681)
+    assert lib.nttx_plan_create(0, 7681, 12345, 16, 1, tab, tab, None, 0, C.byref(plan)) == _lib.NTTX_EINVAL
+    # wrong modulus for the Goldilocks kind
+    assert lib.nttx_plan_create(1, q61, 0, 16, 1, tab, tab, None, 0, C.byref(plan)) == _lib.NTTX_EINVAL
+    # n not a power of two, NULL tables
+    assert lib.nttx_plan_create(0, q61, k61, 12, 1, tab, tab, None, 0, C.byref(plan)) == _lib.NTTX_EINVAL
+    assert lib.nttx_plan_create(0, q61, k61, 16, 1, None, tab, None, 0, C.byref(plan)) == _lib.NTTX_EINVAL
+    assert lib.nttx_plan_create_from_root(0, q61, 3, 8, None, 0, C.byref(plan)) == _lib.NTTX_EINVAL
+    assert lib.nttx_plan_create_from_root(7, q61, 3, 16, None, 0, C.byref(plan)) == _lib.NTTX_EINVAL
+    assert plan.value is None
+    assert lib.nttx_forward_host(None, None, 1) == _lib.NTTX_EINVAL
+    assert lib.nttx_version().startswith(b"nttx")
+
+
+def test_python_utils_mirror_matches_oracle():
+    import _oracle as orc
+    from ntt_amd import utils
+
+    q61 = 0x1FFFFFFFFFE00001
+    assert utils.bit_reverse(2, 2) == 1
+    for bits in (3, 4, 16):
+        for n in range(0, 1 << min(bits, 6)):
+            assert utils.bit_reverse(n, bits) == orc.bit_reverse(n, bits)
+    g, x, y = utils.egcd_i128(q61, 1 << 64)
+    assert g == q61 * x + (1 << 64) * y == 1
+    m = utils.MontgomeryTransformer.from_modulus(q61)
+    assert (m.k, m.r_square) == (6917533425689690113, 281474708275264)
+    o = orc.MontgomeryTransformer.from_modulus(q61)
+    for v in (1, 16777208, q61 - 1):
+        assert m.transform(v) == o.transform(v)
+        assert m.reduce(m.transform(v)) == v
+    assert utils.MontgomeryTransformer.from_modulus(7681).k == orc.MontgomeryTransformer.from_modulus(7681).k
+    assert utils.mod_exp_u64(3, 200, 1000003) == pow(3, 200, 1000003)
+    r = utils.find_nth_unity_root_u64(1 << 17, q61)
+    assert pow(r, 1 << 17, q61) == 1 and pow(r, 1 << 16, q61) == q61 - 1

@@ -1,0 +1,287 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Mirrors the reference's own tests (dft.rs:23-189, ntt.rs:279-295) with the GPU tables in
+place of the CPU ones, and adds every pass shape, batch raggedness and the edge cases the
+reference's arithmetic has (inputs >= q for the base table, the non-canonical q the
+Goldilocks forward can emit, 64-bit moduli through the Montgomery table).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import _oracle as orc
+
+Q61 = 0x1FFFFFFFFFE00001
+PSI61_2_21 = 0x0B4F9CB5C38B40B1   # 37^((q-1)/2^21): primitive 2^21-th root, PSI61 = this^16
+PSI61 = 0x15EB043C7AA2B01F
+QGL = 0xFFFFFFFF00000001
+PSIGL = 0xABD0A6E8AA3D8A0E
+GL_GEN = 7
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).astype("<u8").tobytes()).hexdigest()
+
+
+def psi61_for(n):
+    assert pow(PSI61_2_21, 16, Q61) == PSI61
+    return pow(PSI61_2_21, (1 << 20) // n, Q61)
+
+
+def psigl_for(n):
+    return pow(GL_GEN, (QGL - 1) // (2 * n), QGL)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import ntt_amd
+    return ntt_amd
+
+
+def _batch_check(gpu_tab, orc_tab, q, n, batch, seed, dtype=np.uint64):
+    a0 = orc.splitmix_residues(q, n * batch, seed)
+    want = a0.copy()
+    for b in range(batch):
+        orc_tab.forward_inplace(want[b * n:(b + 1) * n].view(dtype))
+    got = a0.copy().view(dtype)
+    gpu_tab.forward_inplace_batch(got, batch)
+    assert np.array_equal(got.view(np.uint64), want), "forward mismatch"
+    for b in range(batch):
+        orc_tab.backward_inplace(want[b * n:(b + 1) * n].view(dtype))
+    gpu_tab.backward_inplace_batch(got, batch)
+    assert np.array_equal(got.view(np.uint64), want), "backward mismatch"
+    assert np.array_equal(want, a0), "oracle round trip"
+
+
+@pytest.mark.parametrize("logn", [2, 4, 6, 8, 10, 12, 14, 16, 18, 20])
+def test_mont61_all_pass_shapes(amd, logn):
+    n = 1 << logn
+    psi = psi61_for(n)
+    gpu = amd.Table.from_prime_and_root(Q61, psi, n)
+    ref = orc.Table.from_prime_and_root(Q61, psi, n)
+    assert np.array_equal(gpu.powers_psi_bo, ref.powers_psi_bo)
+    assert np.array_equal(gpu.powers_psi_inv_bo, ref.powers_psi_inv_bo)
+    for batch in ([1, 3, 37] if logn <= 16 else [1, 3]):
+        _batch_check(gpu, ref, Q61, n, batch, 1000 + logn * 10 + batch)
+
+
+@pytest.mark.parametrize("logn", [2, 4, 6, 8, 10, 12, 14, 16, 18, 20])
+def test_goldilocks_all_pass_shapes(amd, logn):
+    n = 1 << logn
+    psi = psigl_for(n)
+    gpu = amd.TableGoldilock.from_root(psi, n)
+    ref = orc.TableGoldilock.from_root(psi, n)
+    assert np.array_equal(gpu.powers_psi_bo, ref.powers_psi_bo)
+    assert np.array_equal(gpu.powers_psi_inv_bo, ref.powers_psi_inv_bo)
+    assert gpu.n_inv == ref.n_inv
+    for batch in ([1, 5, 33] if logn <= 16 else [1, 2]):
+        _batch_check(gpu, ref, QGL, n, batch, 2000 + logn * 10 + batch)
+
+
+@pytest.mark.parametrize("logn", [4, 8, 12, 16])
+def test_goldilocks_prime_through_montgomery_table(amd, logn):
+    """Table::new_goldilock (ntt.rs:60-62): a 64-bit modulus in the Montgomery path."""
+    n = 1 << logn
+    psi = psigl_for(n)
+    gpu = amd.Table.from_prime_and_root(QGL, psi, n)
+    ref = orc.Table.from_prime_and_root(QGL, psi, n)
+    _batch_check(gpu, ref, QGL, n, 3, 3000 + logn)
+
+
+def test_base_version(amd):  # dft.rs:23-42
+    table = amd.Table.new_goldilock()
+    a = orc.splitmix_residues(table.q, 1 << 16, 11)
+    a_cloned = a.copy()
+    table.forward_inplace(a)
+    assert np.any(a != a_cloned)
+    table.backward_inplace(a)
+    assert np.array_equal(a, a_cloned)
+
+
+def test_avx_correctness(amd):  # dft.rs:45-78, both sides on the GPU and both against the CPU oracles
+    table, table_avx = amd.Table.new(), amd.TableAVX2.new()
+    o_base, o_avx = orc.Table.new(), orc.TableAVX2.new()
+    a_avx2 = orc.splitmix_residues(table_avx.q, 1 << 16, 12).astype(np.int64)
+    a = a_avx2.astype(np.uint64)
+    a_cloned = a.copy()
+    w_base, w_avx = a.copy(), a_avx2.copy()
+
+    table.forward_inplace(a)
+    table_avx.forward_inplace(a_avx2)
+    o_base.forward_inplace(w_base)
+    o_avx.forward_inplace(w_avx)
+    assert np.array_equal(a, a_avx2.view(np.uint64))
+    assert np.array_equal(a, w_base)
+    assert np.array_equal(a_avx2, w_avx)
+
+    table.backward_inplace(a)
+    table_avx.backward_inplace(a_avx2)
+    o_avx.backward_inplace(w_avx)
+    assert np.array_equal(a, a_avx2.view(np.uint64))
+    assert np.array_equal(a_avx2, w_avx)
+    assert np.array_equal(a, a_cloned)
+
+
+def test_goldilock_correctness(amd):  # dft.rs:127-152
+    table, table_goldilock = amd.Table.new_goldilock(), amd.TableGoldilock.new()
+    a_goldilock = orc.splitmix_residues(table_goldilock.q, 1 << 16, 13)
+    a_cloned = a_goldilock.copy()
+    a = a_goldilock.copy()
+    table.forward_inplace(a)
+    table_goldilock.forward_inplace(a_goldilock)
+    assert np.array_equal(a, a_goldilock)
+    w = a_cloned.copy()
+    orc.TableGoldilock.new().forward_inplace(w)
+    assert np.array_equal(a_goldilock, w)
+    table.backward_inplace(a)
+    table_goldilock.backward_inplace(a_goldilock)
+    assert np.array_equal(a, a_goldilock)
+    assert np.array_equal(a, a_cloned)
+
+
+def test_normal_case(amd):  # ntt.rs:279-295 (`2 ^ 61` is XOR: inputs in 0..63)
+    table = amd.Table.new()
+    a = (orc.splitmix_residues(Q61, 1 << 16, 14) % np.uint64(63)).astype(np.uint64)
+    a_clone = a.copy()
+    table.forward_inplace(a)
+    table.backward_inplace(a)
+    assert np.array_equal(a_clone, a)
+
+
+def test_lazy_methods_equal_strict(amd):  # ntt.rs:31-35: LAZY is never read
+    table = amd.Table.new()
+    a = orc.splitmix_residues(Q61, 1 << 16, 15)
+    b = a.copy()
+    table.forward_inplace(a)
+    table.forward_inplace_lazy(b)
+    assert np.array_equal(a, b)
+    table.backward_inplace(a)
+    table.backward_inplace_lazy(b)
+    assert np.array_equal(a, b)
+
+
+def test_u32_compatible(amd):  # ntt.rs:66-68
+    gpu, ref = amd.Table.new_u32_compatible(), orc.Table.new_u32_compatible()
+    _batch_check(gpu, ref, 4293918721, 1 << 16, 2, 16)
+
+
+def test_base_accepts_any_u64(amd):  # ntt.rs:125-127, 181-183
+    rng = np.random.default_rng(17)
+    for gpu, ref in ((amd.Table.new(), orc.Table.new()), (amd.Table.new_goldilock(), orc.Table.new_goldilock())):
+        raw = rng.integers(0, 2**64, 1 << 16, dtype=np.uint64)
+        raw[:4] = [2**64 - 1, gpu.q, gpu.q + 1, gpu.q - 1]
+        a, w = raw.copy(), raw.copy()
+        gpu.forward_inplace(a)
+        ref.forward_inplace(w)
+        assert np.array_equal(a, w)
+        a, w = raw.copy(), raw.copy()
+        gpu.backward_inplace(a)
+        ref.backward_inplace(w)
+        assert np.array_equal(a, w)
+
+
+def test_goldilocks_any_u64_input(amd):
+    """TableGoldilock has no input reduction; out-of-range inputs follow the same butterfly rules."""
+    rng = np.random.default_rng(18)
+    gpu, ref = amd.TableGoldilock.new(), orc.TableGoldilock.new()
+    raw = rng.integers(0, 2**64, 1 << 16, dtype=np.uint64)
+    raw[:4] = [2**64 - 1, QGL, QGL + 1, QGL - 1]
+    for fn in ("forward_inplace", "backward_inplace"):
+        a, w = raw.copy(), raw.copy()
+        getattr(gpu, fn)(a)
+        getattr(ref, fn)(w)
+        assert np.array_equal(a, w), fn
+
+
+def test_goldilocks_forward_emits_q(amd):
+    """ntt_goldilock.rs:107 (`res > q`): an exact sum of q is stored as q; the kernel reproduces it."""
+    for n in (16, 256, 4096, 1 << 16):
+        psi = psigl_for(n)
+        ref = orc.TableGoldilock.from_root(psi, n)
+        gpu = amd.TableGoldilock.from_root(psi, n)
+        s = int(ref.powers_psi_bo[1])            # stage-1 twiddle
+        v = 12345
+        a = np.zeros(n, dtype=np.uint64)
+        a[n // 2] = v                            # V = v * s
+        a[0] = (QGL - (v * s) % QGL) % QGL       # U + V == q exactly in the first butterfly
+        w = a.copy()
+        ref.forward_inplace(w)
+        assert int((w == np.uint64(QGL)).sum()) > 0, "test vector no longer hits the quirk"
+        g = a.copy()
+        gpu.forward_inplace(g)
+        assert np.array_equal(g, w)
+        gpu.backward_inplace(g)
+        ref.backward_inplace(w)
+        assert np.array_equal(g, w)
+        assert np.array_equal(g, a)
+
+
+def test_zero_and_constant_inputs(amd):
+    for gpu, ref, q in ((amd.Table.new(), orc.Table.new(), Q61),
+                        (amd.TableGoldilock.new(), orc.TableGoldilock.new(), QGL)):
+        for fill in (0, 1, q - 1):
+            a = np.full(1 << 16, fill, dtype=np.uint64)
+            w = a.copy()
+            gpu.forward_inplace(a)
+            ref.forward_inplace(w)
+            assert np.array_equal(a, w)
+            gpu.backward_inplace(a)
+            ref.backward_inplace(w)
+            assert np.array_equal(a, w)
+
+
+def test_golden_digests_on_gpu(amd):
+    with open(os.path.join(GOLDEN, "digests.json")) as fh:
+        gold = json.load(fh)
+    t, tg = amd.Table.new(), amd.TableGoldilock.new()
+    assert sha(t.powers_psi_bo) == gold["table_new.powers_psi_bo"]
+    assert sha(t.powers_psi_inv_bo) == gold["table_new.powers_psi_inv_bo"]
+    assert sha(tg.powers_psi_bo) == gold["goldilock_new.powers_psi_bo"]
+    assert sha(tg.powers_psi_inv_bo) == gold["goldilock_new.powers_psi_inv_bo"]
+    ramp = np.arange(1 << 16, dtype=np.uint64)
+    a = ramp.copy(); t.forward_inplace(a); assert sha(a) == gold["table_new.forward.ramp"]
+    a = ramp.copy(); tg.forward_inplace(a); assert sha(a) == gold["goldilock_new.forward.ramp"]
+    lcg = orc.lcg_residues(Q61, 1 << 16)
+    a = lcg.copy(); t.forward_inplace(a); assert sha(a) == gold["table_new.forward.lcg"]
+    a = lcg.copy(); t.backward_inplace(a); assert sha(a) == gold["table_new.backward.lcg"]
+    lcg = orc.lcg_residues(QGL, 1 << 16)
+    a = lcg.copy(); tg.forward_inplace(a); assert sha(a) == gold["goldilock_new.forward.lcg"]
+    a = lcg.copy(); tg.backward_inplace(a); assert sha(a) == gold["goldilock_new.backward.lcg"]
+
+
+def test_errors_match_reference_panics(amd):
+    with pytest.raises(amd.Panic):
+        amd.Table.new_simple()                          # ntt.rs:72-75: odd log2 n
+    with pytest.raises(amd.Panic):
+        amd.Table.from_prime_and_root(1 << 20, 3, 16)   # utils.rs:144-146
+    t = amd.Table.from_prime_and_root(Q61, psi61_for(256), 256)
+    with pytest.raises(amd.Panic):
+        t.forward_inplace(np.zeros(512, dtype=np.uint64))  # ntt.rs:143: slice longer than the table
+    with pytest.raises(amd.Panic):
+        amd.TableAVX2.from_prime_and_root(Q61, psi61_for(4), 4)
+
+
+def test_device_resident_batch(amd):
+    """nttx_forward_device / nttx_backward_device on a torch tensor, checked on sampled transforms."""
+    import torch
+
+    n, batch = 1 << 16, 64
+    t, ref = amd.Table.new(), orc.Table.new()
+    host = orc.splitmix_residues(Q61, n * batch, 99)
+    dev = torch.from_numpy(host.view(np.int64).copy()).cuda()
+    t.forward_inplace(dev)
+    torch.cuda.synchronize()
+    out = dev.cpu().numpy().view(np.uint64)
+    for b in (0, 1, 31, 63):
+        w = host[b * n:(b + 1) * n].copy()
+        ref.forward_inplace(w)
+        assert np.array_equal(out[b * n:(b + 1) * n], w)
+    t.backward_inplace(dev)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy().view(np.uint64), host)
