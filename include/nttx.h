@@ -101,9 +101,18 @@ int nttx_backward_host(const nttx_plan *plan, uint64_t *data, size_t batch);
 int nttx_forward_device(const nttx_plan *plan, int device, void *dptr, size_t batch, void *hip_stream);
 int nttx_backward_device(const nttx_plan *plan, int device, void *dptr, size_t batch, void *hip_stream);
 
-/* Name and average duration bookkeeping for the benchmark: number of kernel launches one
- * forward (dir = 0) or backward (dir = 1) call issues for this plan and batch. */
-int nttx_launches_per_call(const nttx_plan *plan, size_t batch, int dir);
+/*
+ * Profiling hooks (no counterpart in the reference).  One forward or backward call issues
+ * nttx_pass_count() kernel launches ("passes"); dir = 0 forward, 1 backward, and pass indices
+ * follow execution order for that direction.  nttx_pass_describe writes a short name such as
+ * "fwd strided 4+4 stages 1-8" into buf.  nttx_run_pass_device enqueues ONE pass alone so a
+ * benchmark can bracket it with events on its own stream; run out of sequence it leaves
+ * meaningless data in dptr, so it is for timing only.
+ */
+int nttx_pass_count(const nttx_plan *plan);
+int nttx_pass_describe(const nttx_plan *plan, int dir, int pass_index, char *buf, size_t buf_len);
+int nttx_run_pass_device(const nttx_plan *plan, int device, void *dptr, size_t batch, int dir,
+                         int pass_index, void *hip_stream);
 
 int nttx_device_count(void);
 const char *nttx_last_error(void); /* thread-local, never NULL */

@@ -22,7 +22,9 @@ SYMBOLS = {
     "nttx_backward_host": (C.c_int, [_vp, _vp, _sz]),
     "nttx_forward_device": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp]),
     "nttx_backward_device": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp]),
-    "nttx_launches_per_call": (C.c_int, [_vp, _sz, C.c_int]),
+    "nttx_pass_count": (C.c_int, [_vp]),
+    "nttx_pass_describe": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, _sz]),
+    "nttx_run_pass_device": (C.c_int, [_vp, C.c_int, _vp, _sz, C.c_int, C.c_int, _vp]),
     "nttx_device_count": (C.c_int, []),
     "nttx_last_error": (C.c_char_p, []),
     "nttx_version": (C.c_char_p, []),

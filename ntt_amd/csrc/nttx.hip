@@ -126,7 +126,8 @@ int device_slot(const nttx_plan* plan, int device)
 }
 
 // Enqueues one transform of `batch` vectors at dptr on the current device.
-int enqueue(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream)
+int enqueue(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream,
+            int only_pass = -1)
 {
     if (batch == 0)
         return NTTX_OK;
@@ -139,6 +140,8 @@ int enqueue(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool 
 
     const size_t np = plan->passes.size();
     for (size_t i = 0; i < np; i++) {
+        if (only_pass >= 0 && (size_t)only_pass != i)
+            continue;
         const PassDesc& d = plan->passes[fwd ? i : np - 1 - i];
         PassParams p;
         p.data = dptr;
@@ -225,7 +228,8 @@ int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd)
     return rc;
 }
 
-int run_device(const nttx_plan* plan, int device, void* dptr, size_t batch, void* stream, bool fwd)
+int run_device(const nttx_plan* plan, int device, void* dptr, size_t batch, void* stream, bool fwd,
+               int only_pass = -1)
 {
     if (!plan)
         return fail(NTTX_EINVAL, "plan is NULL");
@@ -240,7 +244,7 @@ int run_device(const nttx_plan* plan, int device, void* dptr, size_t batch, void
     HIP_TRY(hipGetDevice(&cur));
     if (cur != device)
         HIP_TRY(hipSetDevice(device));
-    int rc = enqueue(plan, slot, static_cast<uint64_t*>(dptr), batch, fwd, static_cast<hipStream_t>(stream));
+    int rc = enqueue(plan, slot, static_cast<uint64_t*>(dptr), batch, fwd, static_cast<hipStream_t>(stream), only_pass);
     if (cur != device && cur >= 0)
         (void)hipSetDevice(cur);
     return rc;
@@ -430,12 +434,27 @@ int nttx_backward_device(const nttx_plan* plan, int device, void* dptr, size_t b
     return run_device(plan, device, dptr, batch, hip_stream, false);
 }
 
-int nttx_launches_per_call(const nttx_plan* plan, size_t batch, int dir)
+int nttx_pass_count(const nttx_plan* plan) { return plan ? (int)plan->passes.size() : 0; }
+
+int nttx_pass_describe(const nttx_plan* plan, int dir, int pass_index, char* buf, size_t buf_len)
 {
-    (void)dir;
-    if (!plan || batch == 0)
-        return 0;
-    return (int)plan->passes.size();
+    if (!plan || !buf || buf_len == 0)
+        return fail(NTTX_EINVAL, "bad argument");
+    const int np = (int)plan->passes.size();
+    if (pass_index < 0 || pass_index >= np || (dir != 0 && dir != 1))
+        return fail(NTTX_EINVAL, "pass index or direction out of range");
+    const PassDesc& d = plan->passes[dir == 0 ? pass_index : np - 1 - pass_index];
+    std::snprintf(buf, buf_len, "%s %s %d+%d stages %u-%u", dir == 0 ? "fwd" : "bwd", d.contig ? "contig" : "strided",
+                  d.k1, d.k2, d.s0 + 1, d.s0 + (unsigned)(d.k1 + d.k2));
+    return NTTX_OK;
+}
+
+int nttx_run_pass_device(const nttx_plan* plan, int device, void* dptr, size_t batch, int dir, int pass_index,
+                         void* hip_stream)
+{
+    if (!plan || pass_index < 0 || pass_index >= (int)plan->passes.size() || (dir != 0 && dir != 1))
+        return fail(NTTX_EINVAL, "pass index or direction out of range");
+    return run_device(plan, device, dptr, batch, hip_stream, dir == 0, pass_index);
 }
 
 int nttx_device_count(void)
