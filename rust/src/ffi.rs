@@ -1,0 +1,73 @@
+//! Raw bindings of include/nttx.h plus the one helper the table types share.
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct NttxPlan {
+    _private: [u8; 0],
+}
+
+pub const NTTX_OK: c_int = 0;
+pub const NTTX_MONT64: c_int = 0;
+pub const NTTX_GOLDILOCKS: c_int = 1;
+
+extern "C" {
+    pub fn nttx_plan_create(
+        kind: c_int, q: u64, k: u64, n: u64, n_inv: u64,
+        psi_bo: *const u64, psi_inv_bo: *const u64,
+        devices: *const c_int, n_devices: c_int, out: *mut *mut NttxPlan,
+    ) -> c_int;
+    pub fn nttx_plan_create_from_root(
+        kind: c_int, q: u64, psi: u64, n: u64,
+        devices: *const c_int, n_devices: c_int, out: *mut *mut NttxPlan,
+    ) -> c_int;
+    pub fn nttx_plan_destroy(plan: *mut NttxPlan);
+    pub fn nttx_forward_host(plan: *const NttxPlan, data: *mut u64, batch: usize) -> c_int;
+    pub fn nttx_backward_host(plan: *const NttxPlan, data: *mut u64, batch: usize) -> c_int;
+    pub fn nttx_forward_device(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, stream: *mut c_void) -> c_int;
+    pub fn nttx_backward_device(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, stream: *mut c_void) -> c_int;
+    pub fn nttx_last_error() -> *const c_char;
+}
+
+/// Owned plan handle.  A plan is immutable after creation and the library allows concurrent
+/// calls on it, so the table types stay `Send + Sync` as in the reference.
+pub struct Plan(pub *mut NttxPlan);
+unsafe impl Send for Plan {}
+unsafe impl Sync for Plan {}
+
+impl Drop for Plan {
+    fn drop(&mut self) {
+        unsafe { nttx_plan_destroy(self.0) }
+    }
+}
+
+/// The reference reports errors by panicking; a non-zero status keeps that contract.
+pub fn check(rc: c_int) {
+    if rc != NTTX_OK {
+        let msg = unsafe { CStr::from_ptr(nttx_last_error()) }.to_string_lossy().into_owned();
+        panic!("nttx: {msg}");
+    }
+}
+
+impl Plan {
+    pub fn create(kind: c_int, q: u64, k: u64, n: u64, n_inv: u64, psi_bo: &[u64], psi_inv_bo: &[u64]) -> Self {
+        assert_eq!(psi_bo.len() as u64, n);
+        assert_eq!(psi_inv_bo.len() as u64, n);
+        let mut p = std::ptr::null_mut();
+        check(unsafe {
+            nttx_plan_create(kind, q, k, n, n_inv, psi_bo.as_ptr(), psi_inv_bo.as_ptr(), std::ptr::null(), 0, &mut p)
+        });
+        Plan(p)
+    }
+
+    /// `a.len()` must equal the table size: the reference sizes the transform by the slice
+    /// (ntt.rs:123) but only that length round-trips, and a longer one indexes out of bounds.
+    pub fn forward(&self, a: &mut [u64], n: u64) {
+        assert_eq!(a.len() as u64, n, "slice length does not match the table size");
+        check(unsafe { nttx_forward_host(self.0, a.as_mut_ptr(), 1) });
+    }
+    pub fn backward(&self, a: &mut [u64], n: u64) {
+        assert_eq!(a.len() as u64, n, "slice length does not match the table size");
+        check(unsafe { nttx_backward_host(self.0, a.as_mut_ptr(), 1) });
+    }
+}

@@ -1,0 +1,138 @@
+// The reference's own dft.rs / ntt.rs tests, restated against the C++ host mirror
+// (ntt_amd/host/dft.hpp) with the transforms running on the GPU through libnttx.so.
+// Needs a GPU; tests/test_gpu_host_mirror.py builds and runs it.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../../ntt_amd/host/dft.hpp"
+
+using namespace ntt::dft;
+static int failures = 0;
+#define CHECK(cond)                                                          \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);      \
+            failures++;                                                      \
+        }                                                                    \
+    } while (0)
+
+static std::vector<uint64_t> random_below(uint64_t q, size_t n, uint64_t seed)
+{
+    std::mt19937_64 rng(seed);
+    std::uniform_int_distribution<uint64_t> d(0, q - 1);
+    std::vector<uint64_t> a(n);
+    for (auto& x : a)
+        x = d(rng);
+    return a;
+}
+
+// dft.rs:23-42
+static void base_version()
+{
+    auto table = Table<uint64_t>::new_goldilock();
+    auto a = random_below(table.q, 1 << 16, 1);
+    auto a_cloned = a;
+    table.forward_inplace(a);
+    CHECK(a != a_cloned);
+    table.backward_inplace(a);
+    CHECK(a == a_cloned);
+}
+
+// dft.rs:45-78
+static void avx_correctness()
+{
+    auto table = Table<uint64_t>::new_();
+    auto table_avx = TableAVX2::new_();
+    auto a = random_below((uint64_t)table_avx.q, 1 << 16, 2);
+    std::vector<int64_t> a_avx2(a.begin(), a.end());
+    auto a_cloned = a;
+    table.forward_inplace(a);
+    table_avx.forward_inplace(a_avx2);
+    bool same = true;
+    for (size_t i = 0; i < a.size(); i++)
+        same &= a[i] == (uint64_t)a_avx2[i];
+    CHECK(same);
+    table.backward_inplace(a);
+    table_avx.backward_inplace(a_avx2);
+    same = true;
+    for (size_t i = 0; i < a.size(); i++)
+        same &= a[i] == (uint64_t)a_avx2[i];
+    CHECK(same);
+    CHECK(a == a_cloned);
+}
+
+// dft.rs:127-152
+static void goldilock_correctness()
+{
+    auto table = Table<uint64_t>::new_goldilock();
+    auto table_goldilock = TableGoldilock<uint64_t>::new_();
+    auto a_goldilock = random_below(table_goldilock.q, 1 << 16, 3);
+    auto a_cloned = a_goldilock;
+    auto a = a_goldilock;
+    table.forward_inplace(a);
+    table_goldilock.forward_inplace(a_goldilock);
+    CHECK(a == a_goldilock);
+    table.backward_inplace(a);
+    table_goldilock.backward_inplace(a_goldilock);
+    CHECK(a == a_goldilock);
+    CHECK(a == a_cloned);
+}
+
+// ntt.rs:279-295 (`2 ^ 61` is XOR there: values in 0..63)
+static void test_normal_case()
+{
+    auto table = Table<uint64_t>::new_();
+    auto a = random_below(63, 1 << 16, 4);
+    auto a_clone = a;
+    table.forward_inplace(a);
+    table.backward_inplace(a);
+    CHECK(a_clone == a);
+}
+
+// utils.rs:200-222 and the doctests at utils.rs:9-13, 42-50
+static void utils_tests()
+{
+    using namespace ntt::utils;
+    auto params = MontgomeryTransformer<uint64_t>::from_modulus(0x1fffffffffe00001ull);
+    CHECK((params == MontgomeryTransformer<uint64_t>{6917533425689690113ull, 281474708275264ull, 2305843009211596801ull}));
+    for (uint64_t val : {1ull, 16777208ull})
+        CHECK(val == params.reduce((u128)params.transform(val)));
+    CHECK(bit_reverse(2, 2) == 1);
+    auto [gcd, x, y] = egcd_i128((i128)0x1fffffffffe00001ull, (i128)1 << 64);
+    CHECK(gcd == (i128)0x1fffffffffe00001ull * x + ((i128)1 << 64) * y);
+}
+
+static void panics()
+{
+    bool threw = false;
+    try {
+        Table<uint64_t>::new_simple(); // odd log2 n: the reference panics in with_precomputes
+    } catch (const ntt::Panic&) {
+        threw = true;
+    }
+    CHECK(threw);
+    threw = false;
+    try {
+        auto t = Table<uint64_t>::new_();
+        std::vector<uint64_t> too_long(1 << 17);
+        t.forward_inplace(too_long);
+    } catch (const ntt::Panic&) {
+        threw = true;
+    }
+    CHECK(threw);
+}
+
+int main()
+{
+    utils_tests();
+    base_version();
+    avx_correctness();
+    goldilock_correctness();
+    test_normal_case();
+    panics();
+    if (failures == 0)
+        std::printf("all host-mirror tests passed\n");
+    return failures ? 1 : 0;
+}
