@@ -1,8 +1,18 @@
-// Modular arithmetic for the transform kernels: 64-bit Montgomery (R = 2^64) for any odd
-// modulus below 2^64, and the Goldilocks prime 2^64 - 2^32 + 1 with shift-and-add reduction.
+// Modular arithmetic policies for the transform kernels.
 //
-// Every function is __host__ __device__ so the same code is unit-tested on the CPU
-// (tests/test_arith_host.py builds it with g++) before it runs on a GPU.
+//   Shoup61     moduli below 2^61 through the Montgomery-kind plan (Table<u64>, TableAVX2):
+//               lazy butterflies on residues kept in [0, 8q) (forward) / [0, 4q) (backward),
+//               products by a precomputed quotient (w, floor(w * 2^64 / q)); 9 32x32 multiplies.
+//   Mont<WIDE>  any odd modulus below 2^64 (WIDE: q >= 2^63): strict 64-bit Montgomery, R = 2^64.
+//   Goldilocks  q = 2^64 - 2^32 + 1 with the reference's exact per-butterfly rules.
+//
+// A policy provides: Ctx (plan constants), TwElem (device table entry), Tw (twiddle in
+// registers), load(), ct() / gs() butterflies, gs_last() (stage 1 of the inverse with the n^-1
+// factor folded in, canonical outputs), condition_input() and finish() (canonical residue at the
+// end of the forward transform).
+//
+// Every function is __host__ __device__ so the same code is unit-tested on the CPU before it
+// runs on a GPU.
 #pragma once
 #include <stdint.h>
 
@@ -37,39 +47,221 @@ NTTX_HD uint64_t mul_hi(uint64_t a, uint64_t b)
 #endif
 }
 
-// Constants of one Montgomery plan.  `k` is q^-1 mod 2^64 as the reference's
-// MontgomeryTransformer holds it (utils.rs:130); `r_mod_q` = 2^64 mod q.
+// 32 x 32 + 64 -> 64; callers guarantee no overflow or use only low bits.  On the device this is
+// pinned to v_mad_u64_u32: left to itself hipcc lowers the low-half and high-half uses to
+// v_mul_lo_u32 / v_mul_hi_u32, which issue slower on gfx950 and need extra adds.
+NTTX_HD uint64_t mad32(uint32_t a, uint32_t b, uint64_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+    uint64_t d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+    return d;
+#else
+    return (uint64_t)a * (uint64_t)b + c;
+#endif
+}
+NTTX_HD uint64_t mul32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+    uint64_t d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b) : "vcc");
+    return d;
+#else
+    return (uint64_t)a * (uint64_t)b;
+#endif
+}
+// Same with the second factor wave-uniform (an SGPR on the device: plan constants).
+NTTX_HD uint64_t mad32u(uint32_t a, uint32_t b_uniform, uint64_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+    uint64_t d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c) : "vcc");
+    return d;
+#else
+    return (uint64_t)a * (uint64_t)b_uniform + c;
+#endif
+}
+NTTX_HD uint64_t mul32u(uint32_t a, uint32_t b_uniform)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+    uint64_t d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "s"(b_uniform) : "vcc");
+    return d;
+#else
+    return (uint64_t)a * (uint64_t)b_uniform;
+#endif
+}
+// 32-bit add kept opaque on the device so that it stays a single v_add_u32 on one half of a
+// register pair (hipcc otherwise widens it into a 64-bit add plus two moves).
+NTTX_HD uint32_t add32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+    uint32_t d;
+    asm("v_add_u32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+#else
+    return a + b;
+#endif
+}
+NTTX_HD uint32_t mulhi32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+NTTX_HD uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+NTTX_HD uint32_t lo32(uint64_t x) { return (uint32_t)x; }
+NTTX_HD uint32_t hi32(uint64_t x) { return (uint32_t)(x >> 32); }
+
+// One 16-byte device table entry for policies that keep two words per twiddle.
+struct alignas(16) TwPair {
+    uint64_t w;
+    uint64_t v;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Shoup61: q < 2^61 (so 8q <= 2^64).
+//
+// mul(y, (w, v)) with v = floor(w * 2^64 / q) returns y*w - qhat*q mod 2^64, where qhat is
+// floor(y * v / 2^64) computed from the three upper partial products only (at most 2 short).
+// For any y < 2^64 the exact remainder is below q * (1 + y / 2^64) <= 2q, hence the result lies
+// in [0, 4q) and is congruent to y*w.  Outputs of both reference paths are canonical residues
+// (ntt.rs:173-175, ntt_avx2.rs:276-278), so any exact arithmetic mod q that ends in a canonical
+// value reproduces them.
+struct Shoup61Ctx {
+    uint64_t q, q2, q4;
+    uint64_t nq;   // 2^64 - q
+    TwPair one;    // (1, floor(2^64 / q)): reduces an arbitrary u64 input
+    TwPair scale;  // n^-1 (plain residue) and its quotient
+    TwPair scale1; // tw[1] * n^-1 mod q and its quotient (twiddle of inverse stage 1, pre-scaled)
+};
+
+struct Shoup61 {
+    using Ctx = Shoup61Ctx;
+    using TwElem = TwPair;
+    struct Tw {
+        uint32_t w0, w1, v0, v1;
+    };
+
+    static NTTX_HD Tw make(const TwPair& e) { return Tw{lo32(e.w), hi32(e.w), lo32(e.v), hi32(e.v)}; }
+    static NTTX_HD Tw load(const TwElem* __restrict__ t, uint64_t i, const Ctx&) { return make(t[i]); }
+
+    // Quotient estimate floor(y * v / 2^64) from y1*v1 + hi32(y1*v0) + hi32(y0*v1): the dropped
+    // low parts sum to less than 3 * 2^32, so the estimate is at most 2 short.
+    static NTTX_HD uint64_t quot(uint32_t y0, uint32_t y1, const Tw& t)
+    {
+        const uint32_t ah = mulhi32(y1, t.v0);
+        const uint32_t bh = mulhi32(y0, t.v1);
+        return mad32(y1, t.v1, (uint64_t)ah) + bh;
+    }
+
+    // acc + y*w - qh*q mod 2^64, all by multiply-adds: -q is the 64-bit constant nq, the low
+    // words chain through 64-bit addends (overflow past bit 63 is irrelevant), and of the
+    // 2^32-weight cross terms only the low 32 bits matter.
+    static NTTX_HD uint64_t fold(uint64_t acc, uint32_t y0, uint32_t y1, uint64_t qh, const Tw& t, const Ctx& c)
+    {
+        const uint32_t n0 = lo32(c.nq), n1 = hi32(c.nq);
+        const uint64_t s = mad32(y0, t.w0, mad32u(lo32(qh), n0, acc));
+        const uint64_t x = mad32(y0, t.w1, mad32(y1, t.w0, mad32u(lo32(qh), n1, mul32u(hi32(qh), n0))));
+        return pack64(lo32(s), add32(hi32(s), lo32(x)));
+    }
+
+    // acc + (y * w mod q, lazily in [0, 4q)) for any y; exact mod 2^64.
+    static NTTX_HD uint64_t mul_add(uint64_t acc, uint64_t y, const Tw& t, const Ctx& c)
+    {
+        const uint32_t y0 = lo32(y), y1 = hi32(y);
+        return fold(acc, y0, y1, quot(y0, y1, t), t, c);
+    }
+    static NTTX_HD uint64_t mul(uint64_t y, const Tw& t, const Ctx& c) { return mul_add(0, y, t, c); }
+
+    // x in [0, 2m) -> [0, m)
+    static NTTX_HD uint64_t csub(uint64_t x, uint64_t m)
+    {
+        const uint64_t t = x - m;
+        return (x < m) ? x : t;
+    }
+
+    // Cooley-Tukey, values in [0, 8q) in and out (ntt.rs:146-166 on lazy residues):
+    // a' = u + v, b' = u - v + 4q = (2u + 4q) - a' with u = a mod-ish 4q, v = b*s lazily.
+    static NTTX_HD void ct(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
+    {
+        const uint64_t u = csub(a, c.q4);          // [0, 4q)
+        const uint64_t sum = mul_add(u, b, s, c);  // u + v, v in [0, 4q)
+        const uint64_t t = (u << 1) + c.q4;
+        a = sum;                                   // [0, 8q)
+        b = t - sum;                               // u - v + 4q in (0, 8q)
+    }
+
+    // Gentleman-Sande, values in [0, 4q) in and out (ntt.rs:200-221 on lazy residues).
+    static NTTX_HD void gs(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
+    {
+        const uint64_t u = a, v = b;
+        a = csub(u + v, c.q4);                     // [0, 4q)
+        b = mul((u + c.q4) - v, s, c);             // input (0, 8q) -> [0, 4q)
+    }
+
+    // [0, 4q) -> [0, q)
+    static NTTX_HD uint64_t canon4(uint64_t x, const Ctx& c) { return csub(csub(x, c.q2), c.q); }
+
+    // Stage 1 of the inverse with the n^-1 factor of ntt.rs:231-235 folded in; canonical outputs.
+    static NTTX_HD void gs_last(uint64_t& a, uint64_t& b, const Tw&, const Ctx& c)
+    {
+        const uint64_t u = a, v = b;
+        a = canon4(mul(u + v, make(c.scale), c), c);
+        b = canon4(mul((u + c.q4) - v, make(c.scale1), c), c);
+    }
+
+    // ntt.rs:125-127, 181-183: the reference's first sweep maps any u64 to its residue.
+    static NTTX_HD uint64_t condition_input(uint64_t x, const Ctx& c)
+    {
+        return (x >= c.q) ? canon4(mul(x, make(c.one), c), c) : x;
+    }
+
+    // [0, 8q) -> [0, q): the canonical value ntt.rs:173-175 ends with.
+    static NTTX_HD uint64_t finish(uint64_t x, const Ctx& c) { return canon4(csub(x, c.q4), c); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Strict 64-bit Montgomery on canonical residues.  `k` is q^-1 mod 2^64 as the reference's
+// MontgomeryTransformer holds it (utils.rs:130); twiddles are in Montgomery form as the
+// reference stores them, data stays in plain form: REDC(x * wR) = x * w.
 struct MontCtx {
     uint64_t q;
     uint64_t k;
-    uint64_t r_mod_q;
-    uint64_t n_inv_m; // n^-1 in Montgomery form (ntt.rs:13)
+    uint64_t r_mod_q;  // 2^64 mod q
+    uint64_t n_inv_m;  // n^-1 in Montgomery form (ntt.rs:13)
 };
 
-// Montgomery arithmetic on canonical residues in [0, q).  WIDE selects carry-aware
-// addition for q >= 2^63 (the Goldilocks prime run through Table<u64>, ntt.rs:60-62).
-template <bool WIDE>
+template <bool WIDE> // WIDE: q >= 2^63 needs carry-aware addition (Table::new_goldilock, ntt.rs:60-62)
 struct Mont {
     using Ctx = MontCtx;
+    using TwElem = uint64_t;
+    struct Tw {
+        uint64_t w;
+    };
+
+    static NTTX_HD Tw load(const TwElem* __restrict__ t, uint64_t i, const Ctx&) { return Tw{t[i]}; }
 
     // REDC(a * b): a * b * 2^-64 mod q in [0, q) for a * b < q * 2^64 (utils.rs:165-178).
-    // Because k * q = 1 mod 2^64, the low words of a*b and m*q are equal, so only the
-    // high words need subtracting and the borrow decides the correction.
+    // Because k * q = 1 mod 2^64 the low words of a*b and m*q are equal, so only the high
+    // words need subtracting and the borrow decides the correction.
     static NTTX_HD uint64_t mul(uint64_t a, uint64_t b, const Ctx& c)
     {
         uint64_t hi, lo;
         mul_wide(a, b, hi, lo);
-        uint64_t m = lo * c.k;
-        uint64_t mq_hi = mul_hi(m, c.q);
-        uint64_t r = hi - mq_hi;
+        const uint64_t m = lo * c.k;
+        const uint64_t mq_hi = mul_hi(m, c.q);
+        const uint64_t r = hi - mq_hi;
         return (hi < mq_hi) ? r + c.q : r;
     }
 
     static NTTX_HD uint64_t add(uint64_t u, uint64_t v, const Ctx& c)
     {
-        uint64_t s = u + v;
+        const uint64_t s = u + v;
         if (WIDE) {
-            bool carry = s < u;
+            const bool carry = s < u;
             return (carry || s >= c.q) ? s - c.q : s;
         }
         return (s >= c.q) ? s - c.q : s;
@@ -77,33 +269,58 @@ struct Mont {
 
     static NTTX_HD uint64_t sub(uint64_t u, uint64_t v, const Ctx& c)
     {
-        uint64_t d = u - v;
+        const uint64_t d = u - v;
         return (u < v) ? d + c.q : d;
     }
-    static NTTX_HD uint64_t sub_ct(uint64_t u, uint64_t v, const Ctx& c) { return sub(u, v, c); }
-    static NTTX_HD uint64_t sub_gs(uint64_t u, uint64_t v, const Ctx& c) { return sub(u, v, c); }
 
-    // The reference's first sweep (ntt.rs:125-127, 181-183) maps any u64 to its residue;
-    // REDC(x * (2^64 mod q)) = x mod q does the same for the rare x >= q.
+    static NTTX_HD void ct(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
+    {
+        const uint64_t u = a, v = mul(b, s.w, c);
+        a = add(u, v, c);
+        b = sub(u, v, c);
+    }
+
+    static NTTX_HD void gs(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
+    {
+        const uint64_t u = a, v = b;
+        a = add(u, v, c);
+        b = mul(sub(u, v, c), s.w, c);
+    }
+
+    static NTTX_HD void gs_last(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
+    {
+        const uint64_t u = a, v = b;
+        const uint64_t sf = mul(s.w, c.n_inv_m, c); // (S * n^-1) in Montgomery form
+        a = mul(add(u, v, c), c.n_inv_m, c);
+        b = mul(sub(u, v, c), sf, c);
+    }
+
+    // REDC(x * (2^64 mod q)) = x mod q for the rare x >= q (ntt.rs:125-127, 181-183)
     static NTTX_HD uint64_t condition_input(uint64_t x, const Ctx& c)
     {
         return (x >= c.q) ? mul(x, c.r_mod_q, c) : x;
     }
 
-    // factor applied to every output of the inverse transform (ntt.rs:231-235)
-    static NTTX_HD uint64_t scale_factor(const Ctx& c) { return c.n_inv_m; }
+    static NTTX_HD uint64_t finish(uint64_t x, const Ctx&) { return x; }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Goldilocks arithmetic with the reference's exact per-butterfly rules, so that the forward
+// transform reproduces TableGoldilock bit for bit, including the non-canonical value q that
+// `res > q` (ntt_goldilock.rs:107) lets through.
 struct GoldilocksCtx {
     uint64_t n_inv; // plain residue (ntt_goldilock.rs:12)
 };
 
-// Goldilocks arithmetic with the reference's exact per-butterfly rules, so that the
-// forward transform reproduces TableGoldilock bit for bit, including the non-canonical
-// value q that `res > q` (ntt_goldilock.rs:107) lets through.
 struct Goldilocks {
     using Ctx = GoldilocksCtx;
+    using TwElem = uint64_t;
+    struct Tw {
+        uint64_t w;
+    };
     static constexpr uint64_t Q = 0xffffffff00000001ull;
+
+    static NTTX_HD Tw load(const TwElem* __restrict__ t, uint64_t i, const Ctx&) { return Tw{t[i]}; }
 
     // mul_reduce (ntt_goldilock.rs:183-190) with reduce_159 (:63-79): canonical a*b mod q
     // for any u64 a, b.
@@ -111,12 +328,12 @@ struct Goldilocks {
     {
         uint64_t hi, lo;
         mul_wide(a, b, hi, lo);
-        uint64_t high = hi >> 32;
-        uint64_t middle = hi & 0xffffffffull;
+        const uint64_t high = hi >> 32;
+        const uint64_t middle = hi & 0xffffffffull;
         uint64_t low_2 = lo - high;
         if (lo < high)
             low_2 += Q;
-        uint64_t product = (middle << 32) - middle;
+        const uint64_t product = (middle << 32) - middle;
         uint64_t res = low_2 + product;
         if (res < product || res >= Q)
             res -= Q;
@@ -126,8 +343,8 @@ struct Goldilocks {
     // ntt_goldilock.rs:104-112: carry -> -q, else strictly-greater -> -q (a sum of exactly q stays)
     static NTTX_HD uint64_t add(uint64_t u, uint64_t v, const Ctx&)
     {
-        uint64_t s = u + v;
-        bool carry = s < u;
+        const uint64_t s = u + v;
+        const bool carry = s < u;
         return (carry || s > Q) ? s - Q : s;
     }
 
@@ -143,12 +360,35 @@ struct Goldilocks {
     // ntt_goldilock.rs:162-165: borrow -> +q, no further reduction
     static NTTX_HD uint64_t sub_gs(uint64_t u, uint64_t v, const Ctx&)
     {
-        uint64_t d = u - v;
+        const uint64_t d = u - v;
         return (u < v) ? d + Q : d;
     }
 
+    static NTTX_HD void ct(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
+    {
+        const uint64_t u = a, v = mul(b, s.w, c);
+        a = add(u, v, c);
+        b = sub_ct(u, v, c);
+    }
+
+    static NTTX_HD void gs(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
+    {
+        const uint64_t u = a, v = b;
+        a = add(u, v, c);
+        b = mul(sub_gs(u, v, c), s.w, c);
+    }
+
+    // last stage + mul_reduce(., n_inv) (ntt_goldilock.rs:177-179): both products are canonical
+    static NTTX_HD void gs_last(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
+    {
+        const uint64_t u = a, v = b;
+        const uint64_t sf = mul(s.w, c.n_inv, c);
+        a = mul(add(u, v, c), c.n_inv, c);
+        b = mul(sub_gs(u, v, c), sf, c);
+    }
+
     static NTTX_HD uint64_t condition_input(uint64_t x, const Ctx&) { return x; }
-    static NTTX_HD uint64_t scale_factor(const Ctx& c) { return c.n_inv; }
+    static NTTX_HD uint64_t finish(uint64_t x, const Ctx&) { return x; }
 };
 
 } // namespace nttx

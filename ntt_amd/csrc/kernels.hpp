@@ -30,12 +30,13 @@ constexpr int LDS_ELEMS = TILE + TILE / 16;
 
 enum : uint32_t {
     PASS_CONDITION_INPUT = 1u, // first pass of a transform: map arbitrary u64 input to residues
-    PASS_SCALE = 2u            // pass holding stage 1 of the inverse: fold the n^-1 factor in
+    PASS_SCALE = 2u,           // pass holding stage 1 of the inverse: fold the n^-1 factor in
+    PASS_FINISH = 4u           // last pass of the forward transform: store canonical residues
 };
 
 struct PassParams {
     uint64_t* data;
-    const uint64_t* tw;       // psi_bo (forward) or psi_inv_bo (backward), n entries
+    const void* tw;           // device twiddle table of this direction, n entries of Arith::TwElem
     uint64_t nblocks_total;   // batch << s0
     uint32_t logB;            // log2 of the block size n >> s0
     uint32_t s0;              // stages that precede this pass in forward order
@@ -47,16 +48,16 @@ struct PassParams {
 // tw[(P << (u-1)) + (i >> (K-u+1))], which is the reference's powers_psi_bo[m + i] with
 // m = P << (u-1) (ntt.rs:139-147 forward, :196-221 backward).
 template <class A, int K, bool FWD>
-__device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const uint64_t* __restrict__ tw, uint64_t P,
+__device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const typename A::TwElem* __restrict__ tw, uint64_t P,
                                       const typename A::Ctx& c, bool scale)
 {
     constexpr int M = 1 << K;
-    uint64_t w[M];
+    typename A::Tw w[M];
 #pragma unroll
     for (int u = 1; u <= K; u++) {
 #pragma unroll
         for (int b = 0; b < (1 << (u - 1)); b++)
-            w[(1 << (u - 1)) + b] = tw[(P << (u - 1)) + b];
+            w[(1 << (u - 1)) + b] = A::load(tw, (P << (u - 1)) + b, c);
     }
     if (FWD) {
 #pragma unroll
@@ -64,14 +65,10 @@ __device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const uint64_t* __r
             const int half = M >> u;
 #pragma unroll
             for (int b = 0; b < (1 << (u - 1)); b++) {
-                const uint64_t s = w[(1 << (u - 1)) + b];
 #pragma unroll
                 for (int i = 0; i < half; i++) {
-                    const int lo = b * 2 * half + i, hi = lo + half;
-                    const uint64_t U = x[lo];
-                    const uint64_t V = A::mul(x[hi], s, c);
-                    x[lo] = A::add(U, V, c);
-                    x[hi] = A::sub_ct(U, V, c);
+                    const int lo = b * 2 * half + i;
+                    A::ct(x[lo], x[lo + half], w[(1 << (u - 1)) + b], c);
                 }
             }
         }
@@ -80,25 +77,17 @@ __device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const uint64_t* __r
         for (int u = K; u >= 1; u--) {
             const int half = M >> u;
             if (u == 1 && scale) {
-                // last stage of the inverse: (U+V)*n^-1 and (U-V)*(S*n^-1)  (ntt.rs:231-235)
-                const uint64_t f = A::scale_factor(c);
-                const uint64_t sf = A::mul(w[1], f, c);
+                // last stage of the inverse with the n^-1 factor folded in (ntt.rs:231-235)
 #pragma unroll
-                for (int i = 0; i < half; i++) {
-                    const uint64_t U = x[i], V = x[i + half];
-                    x[i] = A::mul(A::add(U, V, c), f, c);
-                    x[i + half] = A::mul(A::sub_gs(U, V, c), sf, c);
-                }
+                for (int i = 0; i < half; i++)
+                    A::gs_last(x[i], x[i + half], w[1], c);
             } else {
 #pragma unroll
                 for (int b = 0; b < (1 << (u - 1)); b++) {
-                    const uint64_t s = w[(1 << (u - 1)) + b];
 #pragma unroll
                     for (int i = 0; i < half; i++) {
-                        const int lo = b * 2 * half + i, hi = lo + half;
-                        const uint64_t U = x[lo], V = x[hi];
-                        x[lo] = A::add(U, V, c);
-                        x[hi] = A::mul(A::sub_gs(U, V, c), s, c);
+                        const int lo = b * 2 * half + i;
+                        A::gs(x[lo], x[lo + half], w[(1 << (u - 1)) + b], c);
                     }
                 }
             }
@@ -170,6 +159,7 @@ __device__ __forceinline__ void do_round(const PassParams& p, const TileGeom<K1 
     constexpr int M = 1 << KR;
     constexpr int GROUPS = REGS / M;
     constexpr uint32_t logS = TILE_LOG - K;
+    constexpr bool DST_FINAL = ROUND_A ? (K2 == 0) : true; // this round runs the last stage of the pass
     const bool scale = ROUND_A && (p.flags & PASS_SCALE);
     const bool cond = SRC_G && (p.flags & PASS_CONDITION_INPUT);
 
@@ -208,7 +198,12 @@ __device__ __forceinline__ void do_round(const PassParams& p, const TileGeom<K1 
                 x[i] = lds[lds_addr<CONTIG, K>(sigma, r0 + (i << rstep_log))];
         }
 
-        radix<A, KR, FWD>(x, p.tw, ok ? P : 1, c, scale);
+        radix<A, KR, FWD>(x, static_cast<const typename A::TwElem*>(p.tw), ok ? P : 1, c, scale);
+        if (FWD && DST_FINAL && (p.flags & PASS_FINISH)) {
+#pragma unroll
+            for (int i = 0; i < M; i++)
+                x[i] = A::finish(x[i], c);
+        }
 
         if (DST_G) {
             if (ok) {

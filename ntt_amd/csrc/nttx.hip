@@ -41,12 +41,15 @@ struct nttx_plan {
     int kind = 0;
     uint64_t q = 0, k = 0, n = 0, n_inv = 0;
     uint32_t logn = 0;
-    bool wide = false; // q >= 2^63: carry-aware additions
+    // arithmetic policy of the kernels (arith.hpp)
+    enum Policy { SHOUP61, MONT, MONT_WIDE, GOLDILOCKS } policy = MONT;
     nttx::MontCtx mctx{};
+    nttx::Shoup61Ctx sctx{};
     nttx::GoldilocksCtx gctx{};
-    std::vector<uint64_t> h_fwd, h_inv;
+    std::vector<uint64_t> h_fwd, h_inv;       // tables as the caller passed them
+    std::vector<nttx::TwPair> h_fwd2, h_inv2; // SHOUP61: plain twiddle + quotient
     std::vector<int> devices;
-    std::vector<uint64_t*> d_fwd, d_inv; // per device
+    std::vector<void*> d_fwd, d_inv; // per device
     std::vector<PassDesc> passes;        // forward order
 };
 
@@ -154,13 +157,15 @@ int enqueue(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool 
             p.flags |= PASS_CONDITION_INPUT;
         if (!fwd && d.s0 == 0)
             p.flags |= PASS_SCALE;
+        if (fwd && i + 1 == np)
+            p.flags |= PASS_FINISH;
         hipError_t e;
-        if (plan->kind == NTTX_GOLDILOCKS)
-            e = launch_dir<Goldilocks>(fwd, d, p, plan->gctx, (unsigned)tiles, stream);
-        else if (plan->wide)
-            e = launch_dir<Mont<true>>(fwd, d, p, plan->mctx, (unsigned)tiles, stream);
-        else
-            e = launch_dir<Mont<false>>(fwd, d, p, plan->mctx, (unsigned)tiles, stream);
+        switch (plan->policy) {
+        case nttx_plan::GOLDILOCKS: e = launch_dir<Goldilocks>(fwd, d, p, plan->gctx, (unsigned)tiles, stream); break;
+        case nttx_plan::MONT_WIDE: e = launch_dir<Mont<true>>(fwd, d, p, plan->mctx, (unsigned)tiles, stream); break;
+        case nttx_plan::MONT: e = launch_dir<Mont<false>>(fwd, d, p, plan->mctx, (unsigned)tiles, stream); break;
+        default: e = launch_dir<Shoup61>(fwd, d, p, plan->sctx, (unsigned)tiles, stream); break;
+        }
         if (e != hipSuccess)
             return fail(NTTX_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     }
@@ -268,15 +273,18 @@ int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
     }
     int prev = 0;
     (void)hipGetDevice(&prev);
-    const size_t bytes = plan->n * sizeof(uint64_t);
+    const bool pairs = plan->policy == nttx_plan::SHOUP61;
+    const size_t bytes = plan->n * (pairs ? sizeof(nttx::TwPair) : sizeof(uint64_t));
+    const void* src_fwd = pairs ? (const void*)plan->h_fwd2.data() : (const void*)plan->h_fwd.data();
+    const void* src_inv = pairs ? (const void*)plan->h_inv2.data() : (const void*)plan->h_inv.data();
     plan->d_fwd.assign(plan->devices.size(), nullptr);
     plan->d_inv.assign(plan->devices.size(), nullptr);
     for (size_t i = 0; i < plan->devices.size(); i++) {
         HIP_TRY(hipSetDevice(plan->devices[i]));
         HIP_TRY(hipMalloc(&plan->d_fwd[i], bytes));
         HIP_TRY(hipMalloc(&plan->d_inv[i], bytes));
-        HIP_TRY(hipMemcpy(plan->d_fwd[i], plan->h_fwd.data(), bytes, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(plan->d_inv[i], plan->h_inv.data(), bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(plan->d_fwd[i], src_fwd, bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(plan->d_inv[i], src_inv, bytes, hipMemcpyHostToDevice));
     }
     (void)hipSetDevice(prev);
     return NTTX_OK;
@@ -326,12 +334,33 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
     plan->n = n;
     plan->n_inv = n_inv;
     plan->logn = logn;
-    plan->wide = (q >> 63) != 0;
-    plan->mctx = nttx::MontCtx{q, k, (uint64_t)((((unsigned __int128)1) << 64) % q), n_inv};
+    using u128 = unsigned __int128;
+    if (kind == NTTX_GOLDILOCKS)
+        plan->policy = nttx_plan::GOLDILOCKS;
+    else if (q < (1ull << 61))
+        plan->policy = nttx_plan::SHOUP61; // 8q <= 2^64: lazy butterflies
+    else
+        plan->policy = (q >> 63) ? nttx_plan::MONT_WIDE : nttx_plan::MONT;
+    plan->mctx = nttx::MontCtx{q, k, (uint64_t)((((u128)1) << 64) % q), n_inv};
     plan->gctx = nttx::GoldilocksCtx{n_inv};
     try {
         plan->h_fwd.assign(psi_bo, psi_bo + n);
         plan->h_inv.assign(psi_inv_bo, psi_inv_bo + n);
+        if (plan->policy == nttx_plan::SHOUP61) {
+            // The kernels multiply plain data by plain twiddles with a precomputed quotient:
+            // w = REDC(w * 2^64) (utils.rs:165-178), v = floor(w * 2^64 / q).
+            const ntt::utils::MontgomeryTransformer<uint64_t> mt{k, 0, q};
+            auto pair_of = [&](uint64_t plain) { return nttx::TwPair{plain, (uint64_t)(((u128)plain << 64) / q)}; };
+            plan->h_fwd2.resize(n);
+            plan->h_inv2.resize(n);
+            for (uint64_t i = 0; i < n; i++) {
+                plan->h_fwd2[i] = pair_of(mt.reduce((u128)psi_bo[i]));
+                plan->h_inv2[i] = pair_of(mt.reduce((u128)psi_inv_bo[i]));
+            }
+            const uint64_t n_inv_plain = mt.reduce((u128)n_inv);
+            const uint64_t s1 = (uint64_t)(((u128)plan->h_inv2[1].w * n_inv_plain) % q);
+            plan->sctx = nttx::Shoup61Ctx{q, 2 * q, 4 * q, 0 - q, pair_of(1 % q), pair_of(n_inv_plain), pair_of(s1)};
+        }
     } catch (const std::bad_alloc&) {
         delete plan;
         return fail(NTTX_ENOMEM, "out of host memory");

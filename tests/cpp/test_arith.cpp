@@ -1,0 +1,192 @@
+// Host-side unit test of ntt_amd/csrc/arith.hpp: every arithmetic policy is run on the CPU
+// (the header is __host__ __device__) against plain unsigned __int128 arithmetic, including a
+// whole radix-2 transform in the reference's loop order (ntt.rs:129-171, :185-229).
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../../ntt_amd/csrc/arith.hpp"
+#include "../../ntt_amd/host/tables.hpp"
+
+using namespace nttx;
+using u128 = unsigned __int128;
+static int failures = 0;
+#define CHECK(cond)                                                          \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            if (failures < 20)                                               \
+                std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);  \
+            failures++;                                                      \
+        }                                                                    \
+    } while (0)
+
+static uint64_t mulmod(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)((u128)a * b % q); }
+
+static Shoup61Ctx make_shoup_ctx(uint64_t q, uint64_t n_inv_plain, uint64_t s1_plain)
+{
+    auto pair_of = [&](uint64_t w) { return TwPair{w, (uint64_t)(((u128)w << 64) / q)}; };
+    return Shoup61Ctx{q, 2 * q, 4 * q, 0 - q, pair_of(1), pair_of(n_inv_plain), pair_of(s1_plain)};
+}
+
+static void shoup_mul_bounds(uint64_t q)
+{
+    std::mt19937_64 rng(q);
+    Shoup61Ctx c = make_shoup_ctx(q, 1, 1);
+    const uint64_t ys[] = {0, 1, q - 1, q, 2 * q, 4 * q - 1, 8 * q - 1, ~0ull, 0xffffffffull, 0x100000000ull};
+    for (int it = 0; it < 200000; it++) {
+        uint64_t w = it < 4 ? (uint64_t[]){0, 1, q - 1, q / 2}[it] : rng() % q;
+        uint64_t y = it % 16 < 10 ? ys[it % 16] : rng();
+        Shoup61::Tw t = Shoup61::make(TwPair{w, (uint64_t)(((u128)w << 64) / q)});
+        uint64_t r = Shoup61::mul(y, t, c);
+        CHECK(r < 4 * q);
+        CHECK(r % q == mulmod(y % q, w, q));
+        uint64_t acc = rng() % (4 * q);
+        CHECK(Shoup61::mul_add(acc, y, t, c) == acc + r);
+    }
+}
+
+// Whole transform with a policy, radix-2, reference loop order; tables in the policy's format.
+template <class A>
+static void forward(std::vector<uint64_t>& a, const std::vector<typename A::TwElem>& tw, const typename A::Ctx& c)
+{
+    const size_t n = a.size();
+    for (auto& x : a)
+        x = A::condition_input(x, c);
+    size_t t = n, m = 1;
+    while (m < n) {
+        t /= 2;
+        for (size_t i = 0; i < m; i++) {
+            typename A::Tw s = A::load(tw.data(), m + i, c);
+            for (size_t j = 2 * i * t; j < 2 * i * t + t; j++)
+                A::ct(a[j], a[j + t], s, c);
+        }
+        m *= 2;
+    }
+    for (auto& x : a)
+        x = A::finish(x, c);
+}
+
+template <class A>
+static void backward(std::vector<uint64_t>& a, const std::vector<typename A::TwElem>& tw, const typename A::Ctx& c)
+{
+    const size_t n = a.size();
+    for (auto& x : a)
+        x = A::condition_input(x, c);
+    size_t t = 1, m = n;
+    while (m > 1) {
+        size_t j1 = 0, h = m / 2;
+        for (size_t i = 0; i < h; i++) {
+            typename A::Tw s = A::load(tw.data(), h + i, c);
+            for (size_t j = j1; j < j1 + t; j++) {
+                if (m == 2)
+                    A::gs_last(a[j], a[j + t], s, c);
+                else
+                    A::gs(a[j], a[j + t], s, c);
+            }
+            j1 += 2 * t;
+        }
+        t *= 2;
+        m /= 2;
+    }
+}
+
+// plain-arithmetic reference of the same transform (canonical residues)
+static void ref_forward(std::vector<uint64_t>& a, const std::vector<uint64_t>& w, uint64_t q)
+{
+    const size_t n = a.size();
+    for (auto& x : a) x %= q;
+    size_t t = n, m = 1;
+    while (m < n) {
+        t /= 2;
+        for (size_t i = 0; i < m; i++)
+            for (size_t j = 2 * i * t; j < 2 * i * t + t; j++) {
+                uint64_t u = a[j], v = mulmod(a[j + t], w[m + i], q);
+                a[j] = (uint64_t)(((u128)u + v) % q);
+                a[j + t] = (uint64_t)(((u128)u + q - v) % q);
+            }
+        m *= 2;
+    }
+}
+
+static void transform_tests(uint64_t q, uint64_t psi, size_t n)
+{
+    auto mt = ntt::host::build_montgomery_tables(q, psi, n);
+    const auto& M = mt.montgomery;
+    std::vector<uint64_t> plain_f(n), plain_b(n);
+    for (size_t i = 0; i < n; i++) {
+        plain_f[i] = M.reduce((u128)mt.powers_psi_bo[i]);
+        plain_b[i] = M.reduce((u128)mt.powers_psi_inv_bo[i]);
+    }
+    std::mt19937_64 rng(n ^ q);
+    std::vector<uint64_t> in(n);
+    for (auto& x : in) x = rng();
+    in[0] = ~0ull; in[1] = q; in[2] = q - 1; in[3] = 0;
+    std::vector<uint64_t> want = in;
+    ref_forward(want, plain_f, q);
+
+    // strict Montgomery (both widths) on Montgomery-form tables
+    MontCtx mc{q, M.k, (uint64_t)((((u128)1) << 64) % q), mt.n_inv_montgomery};
+    {
+        std::vector<uint64_t> a = in;
+        forward<Mont<true>>(a, mt.powers_psi_bo, mc);
+        CHECK(a == want);
+        backward<Mont<true>>(a, mt.powers_psi_inv_bo, mc);
+        for (size_t i = 0; i < n; i++) CHECK(a[i] == in[i] % q);
+    }
+    if (q < (1ull << 63)) {
+        std::vector<uint64_t> a = in;
+        forward<Mont<false>>(a, mt.powers_psi_bo, mc);
+        CHECK(a == want);
+        backward<Mont<false>>(a, mt.powers_psi_inv_bo, mc);
+        for (size_t i = 0; i < n; i++) CHECK(a[i] == in[i] % q);
+    }
+    if (q < (1ull << 61)) {
+        auto pair_of = [&](uint64_t w) { return TwPair{w, (uint64_t)(((u128)w << 64) / q)}; };
+        std::vector<TwPair> f2(n), b2(n);
+        for (size_t i = 0; i < n; i++) { f2[i] = pair_of(plain_f[i]); b2[i] = pair_of(plain_b[i]); }
+        const uint64_t n_inv = M.reduce((u128)mt.n_inv_montgomery);
+        Shoup61Ctx sc = make_shoup_ctx(q, n_inv, mulmod(plain_b[1], n_inv, q));
+        std::vector<uint64_t> a = in;
+        forward<Shoup61>(a, f2, sc);
+        CHECK(a == want);
+        backward<Shoup61>(a, b2, sc);
+        for (size_t i = 0; i < n; i++) CHECK(a[i] == in[i] % q);
+    }
+}
+
+static void goldilocks_tests()
+{
+    const uint64_t q = Goldilocks::Q;
+    GoldilocksCtx c{0};
+    std::mt19937_64 rng(5);
+    const uint64_t v[] = {0, 1, q - 1, q, q + 1, ~0ull, 0xffffffffull, 0x100000000ull};
+    for (int it = 0; it < 100000; it++) {
+        uint64_t a = it % 4 == 0 ? v[(it / 4) % 8] : rng(), b = it % 8 == 1 ? v[(it / 8) % 8] : rng();
+        CHECK(Goldilocks::mul(a, b, c) == mulmod(a % q, b % q, q));
+    }
+    CHECK(Goldilocks::add(q - 5, 5, c) == q);      // ntt_goldilock.rs:107: a sum of exactly q stays q
+    CHECK(Goldilocks::add(q - 5, 6, c) == 1);
+    CHECK(Goldilocks::sub_ct(q, 0, c) == 0);        // :120
+    CHECK(Goldilocks::sub_gs(q, 0, c) == q);        // :162-165
+}
+
+int main()
+{
+    const uint64_t q61 = 0x1fffffffffe00001ull, psi61 = 0x15eb043c7aa2b01full;
+    shoup_mul_bounds(q61);
+    shoup_mul_bounds(4293918721ull);
+    shoup_mul_bounds((1ull << 61) - 1); // not prime; bounds and congruence hold for any odd modulus
+    shoup_mul_bounds(7681);
+    for (size_t n : {4, 16, 256, 4096}) {
+        transform_tests(q61, ntt::utils::mod_exp_u64(psi61, (1 << 16) / n, q61), n);
+        transform_tests(Goldilocks::Q, ntt::utils::mod_exp_u64(0xabd0a6e8aa3d8a0eull, (1 << 16) / n, Goldilocks::Q), n);
+        transform_tests(4293918721ull, ntt::utils::mod_exp_u64(2004365341ull, (1 << 16) / n, 4293918721ull), n);
+    }
+    goldilocks_tests();
+    if (failures == 0)
+        std::printf("all arithmetic tests passed\n");
+    else
+        std::printf("%d failures\n", failures);
+    return failures ? 1 : 0;
+}

@@ -51,6 +51,15 @@ __global__ __launch_bounds__(256) void k(uint64_t* out, uint32_t seed)
                 double d = __longlong_as_double((acc[i] & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
                 d = fma(d, 1.0000001, 1e-9);
                 acc[i] = __double_as_longlong(d);
+            } else if (OP == 10) {  // 64-bit add via v_lshl_add_u64 (non-constant addend)
+                acc[i] = acc[i] + acc[(i + 1) % ILP];
+            } else if (OP == 11) {  // 64-bit compare + select
+                acc[i] = (acc[i] < acc[(i + 1) % ILP]) ? acc[i] + 1 : acc[(i + 3) % ILP];
+            } else if (OP == 12) {  // 32-bit add3
+                uint32_t a = (uint32_t)acc[i];
+                acc[i] = a + x + (uint32_t)acc[(i + 1) % ILP];
+            } else if (OP == 13) {  // 64-bit sub
+                acc[i] = acc[i] - acc[(i + 1) % ILP];
             } else if (OP == 9) {  // v_mad_u32_u24
                 uint32_t a = (uint32_t)acc[i];
                 acc[i] = __umul24(a, x) + a;
@@ -106,5 +115,9 @@ int main()
     run<6>("mul64 lo", 1);
     run<7>("montmul generic", 1);
     run<8>("dfma (+and/or)", 1);
+    run<10>("add64 reg+reg", 1);
+    run<11>("cmp64+select+add", 1);
+    run<12>("add3 u32", 1);
+    run<13>("sub64 reg-reg", 1);
     return 0;
 }
