@@ -1,7 +1,9 @@
 // libnttx: plans, pass scheduling and the C ABI declared in include/nttx.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -128,15 +130,11 @@ int device_slot(const nttx_plan* plan, int device)
     return -1;
 }
 
-// Enqueues one transform of `batch` vectors at dptr on the current device.
-int enqueue(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream,
-            int only_pass = -1)
+// Enqueues the passes of one transform direction for `batch` vectors at dptr.
+int enqueue_passes(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream,
+                   int only_pass)
 {
-    if (batch == 0)
-        return NTTX_OK;
     const uint64_t total = (uint64_t)batch << plan->logn;
-    if ((total >> plan->logn) != batch || total > (1ull << 40))
-        return fail(NTTX_EINVAL, "batch * n is too large");
     const uint64_t tiles = (total + TILE - 1) / TILE;
     if (tiles > 0x7fffffffull)
         return fail(NTTX_EINVAL, "batch * n is too large for one launch");
@@ -159,6 +157,9 @@ int enqueue(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool 
             p.flags |= PASS_SCALE;
         if (fwd && i + 1 == np)
             p.flags |= PASS_FINISH;
+        static const bool no_math = std::getenv("NTTX_DEBUG_NO_MATH") != nullptr;
+        if (no_math)
+            p.flags |= PASS_DEBUG_NO_MATH;
         hipError_t e;
         switch (plan->policy) {
         case nttx_plan::GOLDILOCKS: e = launch_dir<Goldilocks>(fwd, d, p, plan->gctx, (unsigned)tiles, stream); break;
@@ -168,6 +169,45 @@ int enqueue(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool 
         }
         if (e != hipSuccess)
             return fail(NTTX_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    }
+    return NTTX_OK;
+}
+
+// Bytes of batch data that one group of launches covers before the next pass revisits them.
+// A transform of more than one pass re-reads what the previous pass wrote; keeping that span
+// inside the 256 MiB Infinity Cache lets the re-read (and the overwrite of the intermediate
+// values) meet in cache instead of HBM.  NTTX_CHUNK_MIB overrides (0 = whole batch at once).
+size_t chunk_bytes()
+{
+    static const size_t v = [] {
+        const char* e = std::getenv("NTTX_CHUNK_MIB");
+        long mib = e ? std::atol(e) : 64;
+        return mib <= 0 ? (size_t)0 : (size_t)mib << 20;
+    }();
+    return v;
+}
+
+// Enqueues one transform of `batch` vectors at dptr on the current device.
+int enqueue(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream,
+            int only_pass = -1)
+{
+    if (batch == 0)
+        return NTTX_OK;
+    const uint64_t total = (uint64_t)batch << plan->logn;
+    if ((total >> plan->logn) != batch || total > (1ull << 40))
+        return fail(NTTX_EINVAL, "batch * n is too large");
+    size_t per = batch;
+    const size_t cb = chunk_bytes();
+    if (only_pass < 0 && plan->passes.size() > 1 && cb != 0) {
+        per = cb >> (plan->logn + 3);
+        if (per == 0)
+            per = 1;
+    }
+    for (size_t first = 0; first < batch; first += per) {
+        const size_t count = std::min(per, batch - first);
+        int rc = enqueue_passes(plan, slot, dptr + ((uint64_t)first << plan->logn), count, fwd, stream, only_pass);
+        if (rc != NTTX_OK)
+            return rc;
     }
     return NTTX_OK;
 }

@@ -1,0 +1,42 @@
+"""Times every pass kernel of a plan with events (min/median over reps)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ctypes as C
+import torch
+import ntt_amd
+from ntt_amd._lib import lib
+
+kind = sys.argv[1] if len(sys.argv) > 1 else "mont"
+logn = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else (1 << 28) >> logn
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+n = 1 << logn
+if kind == "mont":
+    q = 0x1FFFFFFFFFE00001
+    t = ntt_amd.Table.from_prime_and_root(q, pow(0x0B4F9CB5C38B40B1, (1 << 20) // n, q), n)
+elif kind == "montwide":
+    q = 0xFFFFFFFF00000001
+    t = ntt_amd.Table.from_prime_and_root(q, pow(7, (q - 1) // (2 * n), q), n)
+else:
+    q = 0xFFFFFFFF00000001
+    t = ntt_amd.TableGoldilock.from_root(pow(7, (q - 1) // (2 * n), q), n)
+data = torch.randint(0, min(q, 2**63 - 1), (batch * n,), dtype=torch.int64, device="cuda")
+s = torch.cuda.current_stream()
+tot = 0
+for d in (0, 1):
+    for p in range(lib.nttx_pass_count(t._plan)):
+        buf = C.create_string_buffer(96)
+        lib.nttx_pass_describe(t._plan, d, p, buf, 96)
+        ev = []
+        for r in range(reps + 2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            assert lib.nttx_run_pass_device(t._plan, 0, data.data_ptr(), batch, d, p, s.cuda_stream) == 0
+            e1.record(s)
+            ev.append((e0, e1))
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ev[2:])
+        tot += ms[len(ms) // 2]
+        print("%-32s min %.4f  med %.4f ms" % (buf.value.decode(), ms[0], ms[len(ms) // 2]))
+print("sum of medians %.4f ms -> %.0f pairs/s" % (tot, batch / (tot * 1e-3)))
