@@ -24,9 +24,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 Q61 = 0x1FFFFFFFFFE00001
 PSI61 = 0x15EB043C7AA2B01F
-LOGN = 16
-N = 1 << LOGN
+QGL = 0xFFFFFFFF00000001
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, GB/s
+
+# name -> (kind, log2 n, default batch per GPU, description)
+WORKLOADS = {
+    "mont16": ("mont", 16, 4096, "batch %d x N=2^16 Montgomery 61-bit fwd+inv per GPU (BASELINE configs[1])"),
+    "goldilocks20": ("goldilocks", 20, 256, "batch %d x N=2^20 Goldilocks fwd+inv per GPU (BASELINE configs[2])"),
+    "goldilocks16": ("goldilocks", 16, 4096, "batch %d x N=2^16 Goldilocks fwd+inv per GPU"),
+}
 
 
 def main():
@@ -34,7 +40,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="transforms per GPU")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mont16")
+    ap.add_argument("--batch", type=int, default=0, help="transforms per GPU (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=10, help="event-timed launches per kernel for the roofline")
     args = ap.parse_args()
@@ -44,6 +51,10 @@ def main():
 
     import ntt_amd
     from ntt_amd._lib import lib
+    from ntt_amd.sharding import job_throughput, max_over_ranks
+
+    kind, LOGN, default_batch, describe = WORKLOADS[args.workload]
+    N = 1 << LOGN
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -65,18 +76,32 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
-    batch = args.batch
-    table = ntt_amd.Table.from_prime_and_root(Q61, PSI61, N, devices=[local_rank])
+    batch = args.batch or default_batch
+    import _oracle as orc
+    if kind == "mont":
+        q = Q61
+        table = ntt_amd.Table.from_prime_and_root(Q61, PSI61, N, devices=[local_rank])
+        oracle = orc.Table.new()
+    else:
+        q = QGL
+        psi = pow(7, (QGL - 1) // (2 * N), QGL)
+        table = ntt_amd.TableGoldilock.from_root(psi, N, devices=[local_rank])
+        oracle = orc.TableGoldilock.from_root(psi, N)
 
     # synthetic uniform residues in [0, q), generated on the device
     gen = torch.Generator(device=dev)
     gen.manual_seed(0x5EED0000 + rank)
-    data = torch.randint(0, Q61, (batch * N,), dtype=torch.int64, device=dev, generator=gen)
+    if q < 2**63:
+        data = torch.randint(0, q, (batch * N,), dtype=torch.int64, device=dev, generator=gen)
+    else:  # uniform in [0, q) for a 64-bit q: 64 random bits, the few values >= q folded back
+        hi = torch.randint(0, 2**32, (batch * N,), dtype=torch.int64, device=dev, generator=gen)
+        lo = torch.randint(0, 2**32, (batch * N,), dtype=torch.int64, device=dev, generator=gen)
+        hi = torch.where(hi == 2**32 - 1, hi - 1, hi)  # below 0xffffffff00000000 < q
+        data = (hi << 32) | lo
+        del hi, lo
     original = data.clone()
 
     # correctness outside the timed region: sampled transforms against the oracle, full round trip
-    import _oracle as orc
-    oracle = orc.Table.new()
     table.forward_inplace(data)
     torch.cuda.synchronize()
     for b in sorted({0, batch // 2, batch - 1}):
@@ -102,15 +127,11 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dist, dev)
     if not torch.equal(data, original):
         raise SystemExit("round trip failure after the timed region")
 
-    pairs = batch * world * args.steps
-    value = pairs / elapsed
+    value = job_throughput(batch, world, args.steps, elapsed)
     frac_job = value * 32 * N / (world * HBM_PEAK_GBS * 1e9)
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, per pass -----------
@@ -135,14 +156,21 @@ def main():
             ms = [a.elapsed_time(b) for a, b in evs[2:]]
             kernels.append({"name": buf.value.decode(), "avg_ms": sum(ms) / len(ms)})
     dom = max(kernels, key=lambda k: k["avg_ms"])
-    stages_per_pass = LOGN // npass
     # algorithmic bytes: 16*N per transform (8N read + 8N written once), apportioned to a launch
-    # by the share of the log2(N) stages it executes
-    alg_bytes = 16 * N * batch * stages_per_pass / LOGN
+    # by the share of the log2(N) stages it executes ("... stages a-b" in the pass name)
+    a, b = dom["name"].rsplit(" ", 1)[1].split("-")
+    alg_bytes = 16 * N * batch * (int(b) - int(a) + 1) / LOGN
     achieved = alg_bytes / (dom["avg_ms"] * 1e-3) / 1e9
+    # HBM bytes per launch of that kernel from the PMC passes recorded under profiles/ (FETCH_SIZE
+    # doubled as the gfx950 guide prescribes, plus WRITE_SIZE), if one was taken for this workload
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(tpath) and batch == default_batch:
+        with open(tpath) as fh:
+            traffic = json.load(fh).get(dom["name"])
     roofline = {
         "bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom["avg_ms"], 4),
         "whole_job_frac": round(frac_job, 4),
         "kernels": [{"name": k["name"], "avg_ms": round(k["avg_ms"], 4)} for k in kernels],
@@ -152,30 +180,32 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = max(1, min(16, len(os.sched_getaffinity(0))))
-        per_thread = 150
-        secs = orc.bench_pairs(0, oracle, N, per_thread, cores)
+        okind = 0 if kind == "mont" else 2
+        per_thread = max(2, (150 << 16) >> LOGN if kind == "mont" else (40 << 16) >> LOGN)
+        secs = orc.bench_pairs(okind, oracle, N, per_thread, cores)
         single = {}
-        for kind, name, tab in ((0, "base", oracle), (1, "avx2", orc.TableAVX2.new()),
-                                (2, "goldilock", orc.TableGoldilock.new())):
-            single[name + "_ms_30_pairs_1_thread"] = round(orc.bench_pairs(kind, tab, N, 30, 1) * 1e3, 1)
+        for k2, name, tab in ((0, "base", orc.Table.new()), (1, "avx2", orc.TableAVX2.new()),
+                              (2, "goldilock", orc.TableGoldilock.new())):
+            single[name + "_ms_30_pairs_1_thread"] = round(orc.bench_pairs(k2, tab, 1 << 16, 30, 1) * 1e3, 1)
         cpu = {
             "value": round(cores * per_thread / secs, 1), "unit": "fwd+inv NTT pairs/s", "cores": cores,
             "kind": "port",
-            "sample": "%d threads x %d pairs, N=2^16, q=0x1fffffffffe00001, scalar Montgomery Table (C oracle)"
-                      % (cores, per_thread),
+            "sample": "%d threads x %d pairs, N=2^%d, %s (C oracle)"
+                      % (cores, per_thread, LOGN, "scalar Montgomery Table, q=0x1fffffffffe00001" if kind == "mont"
+                         else "TableGoldilock"),
             "readme_shape": single,
         }
 
     if rank == 0:
         out = {
-            "metric": "batched N=2^16 fwd+inv NTTs/sec per node; % of HBM roofline",
+            "metric": "batched N=2^%d fwd+inv NTTs/sec per node; %% of HBM roofline" % LOGN,
             "value": round(value, 1), "unit": "fwd+inv NTT pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "batch %d x N=2^16 Montgomery 61-bit fwd+inv per GPU (BASELINE configs[1])" % batch,
-                       "batch_per_gpu": batch, "n": N, "modulus": hex(Q61), "sharding": "batch split, no collective"},
+            "config": {"workload": describe % batch, "batch_per_gpu": batch, "n": N, "modulus": hex(q),
+                       "sharding": "batch split, no collective"},
             "hbm_roofline_frac": round(frac_job, 4),
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -173,15 +173,16 @@ int enqueue_passes(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch
     return NTTX_OK;
 }
 
-// Bytes of batch data that one group of launches covers before the next pass revisits them.
-// A transform of more than one pass re-reads what the previous pass wrote; keeping that span
-// inside the 256 MiB Infinity Cache lets the re-read (and the overwrite of the intermediate
-// values) meet in cache instead of HBM.  NTTX_CHUNK_MIB overrides (0 = whole batch at once).
+// Optional chunking of a batch: with NTTX_CHUNK_MIB=<m> all passes run over m MiB of the batch
+// before the next m MiB, so that a pass re-reads what the previous one wrote while it may still
+// sit in the 256 MiB Infinity Cache.  Measured on MI355X this gains at most a few percent at
+// 256 MiB and loses at smaller chunks (more launch boundaries and partial waves of workgroups),
+// so the default is the whole batch per launch.
 size_t chunk_bytes()
 {
     static const size_t v = [] {
         const char* e = std::getenv("NTTX_CHUNK_MIB");
-        long mib = e ? std::atol(e) : 64;
+        long mib = e ? std::atol(e) : 0;
         return mib <= 0 ? (size_t)0 : (size_t)mib << 20;
     }();
     return v;

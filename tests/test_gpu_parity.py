@@ -285,3 +285,41 @@ def test_device_resident_batch(amd):
     t.backward_inplace(dev)
     torch.cuda.synchronize()
     assert np.array_equal(dev.cpu().numpy().view(np.uint64), host)
+
+
+@pytest.mark.parametrize("workload", ["mont16", "goldilocks20"])
+def test_baseline_sizes_device_resident(amd, workload):
+    """BASELINE.json configs[1] / configs[2] at full size on the device: sampled transforms against
+    the oracle, linearity across the batch, and the round trip over every element."""
+    import torch
+
+    if workload == "mont16":
+        n, batch, q = 1 << 16, 4096, Q61
+        gpu, ref = amd.Table.new(), orc.Table.new()
+    else:
+        n, batch, q = 1 << 20, 256, QGL
+        psi = psigl_for(n)
+        gpu, ref = amd.TableGoldilock.from_root(psi, n), orc.TableGoldilock.from_root(psi, n)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234)
+    hi = torch.randint(0, min(q >> 32, 2**32 - 1), (batch * n,), dtype=torch.int64, device="cuda", generator=gen)
+    lo = torch.randint(0, 2**32, (batch * n,), dtype=torch.int64, device="cuda", generator=gen)
+    data = (hi << 32) | lo          # < q by construction of the high word
+    del hi, lo
+    # linearity: transform[0] + transform[1] == transform of (vec0 + vec1), planted in slot 2
+    s = data[0:n].cpu().numpy().view(np.uint64).astype(object) + data[n:2 * n].cpu().numpy().view(np.uint64).astype(object)
+    s = np.array([int(v) % q for v in s], dtype=np.uint64)
+    data[2 * n:3 * n] = torch.from_numpy(s.view(np.int64)).cuda()
+    original = data.clone()
+    gpu.forward_inplace(data)
+    torch.cuda.synchronize()
+    out = [data[b * n:(b + 1) * n].cpu().numpy().view(np.uint64) for b in (0, 1, 2)]
+    lin = np.array([(int(a) + int(b)) % q for a, b in zip(out[0] % np.uint64(q), out[1] % np.uint64(q))], dtype=np.uint64)
+    assert np.array_equal(out[2] % np.uint64(q), lin)
+    for b in (0, batch // 2 + 1, batch - 1):
+        want = original[b * n:(b + 1) * n].cpu().numpy().view(np.uint64).copy()
+        ref.forward_inplace(want)
+        assert np.array_equal(data[b * n:(b + 1) * n].cpu().numpy().view(np.uint64), want)
+    gpu.backward_inplace(data)
+    torch.cuda.synchronize()
+    assert torch.equal(data, original)
