@@ -32,12 +32,14 @@ enum : uint32_t {
     PASS_CONDITION_INPUT = 1u, // first pass of a transform: map arbitrary u64 input to residues
     PASS_SCALE = 2u,           // pass holding stage 1 of the inverse: fold the n^-1 factor in
     PASS_FINISH = 4u,          // last pass of the forward transform: store canonical residues
-    PASS_DEBUG_NO_MATH = 8u    // profiling aid (NTTX_DEBUG_NO_MATH=1): skip the butterflies, keep all traffic
+    PASS_DEBUG_NO_MATH = 8u,   // profiling aid (NTTX_DEBUG_NO_MATH=1): skip the butterflies, keep all traffic
+    PASS_DEBUG_NO_TW = 16u     // profiling aid (NTTX_DEBUG_NO_TW=1, with NO_MATH): skip the twiddle loads too
 };
 
 struct PassParams {
     uint64_t* data;
     const void* tw;           // device twiddle table of this direction, n entries of Arith::TwElem
+    const void* tw_perm;      // same entries with the last four stages regrouped (see permuted_index)
     uint64_t nblocks_total;   // batch << s0
     uint32_t logB;            // log2 of the block size n >> s0
     uint32_t s0;              // stages that precede this pass in forward order
@@ -60,12 +62,25 @@ __device__ __forceinline__ void load_twiddles(typename A::Tw (&w)[1 << K], const
     }
 }
 
+// Twiddle sources for radix(): entry `i` (1 <= i < 2^K) is the twiddle of stage
+// u = floor(log2 i) + 1, block b = i - 2^(u-1).
+template <class A, int K>
+struct RegTw { // preloaded registers
+    const typename A::Tw (&w)[1 << K];
+    __device__ __forceinline__ typename A::Tw get(int i) const { return w[i]; }
+};
+template <class A>
+struct LdsTw { // one 16-entry set staged in LDS, read where it is used
+    const typename A::TwElem* set;
+    const typename A::Ctx& c;
+    __device__ __forceinline__ typename A::Tw get(int i) const { return A::load(set, i, c); }
+};
+
 // K butterfly stages on 2^K registers.  Register i holds sub-transform element i (stride
-// handled by the caller); stage u = 1..K pairs i with i + 2^(K-u) and uses twiddle
-// w[(1 << (u-1)) + (i >> (K-u+1))].
-template <class A, int K, bool FWD>
-__device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const typename A::Tw (&w)[1 << K],
-                                      const typename A::Ctx& c, bool scale)
+// handled by the caller); stage u = 1..K pairs i with i + 2^(K-u) and uses twiddle entry
+// (1 << (u-1)) + (i >> (K-u+1)) of the source.
+template <class A, int K, bool FWD, class Src>
+__device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const Src& w, const typename A::Ctx& c, bool scale)
 {
     constexpr int M = 1 << K;
     if (FWD) {
@@ -74,10 +89,11 @@ __device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const typename A::T
             const int half = M >> u;
 #pragma unroll
             for (int b = 0; b < (1 << (u - 1)); b++) {
+                const typename A::Tw s = w.get((1 << (u - 1)) + b);
 #pragma unroll
                 for (int i = 0; i < half; i++) {
                     const int lo = b * 2 * half + i;
-                    A::ct(x[lo], x[lo + half], w[(1 << (u - 1)) + b], c);
+                    A::ct(x[lo], x[lo + half], s, c);
                 }
             }
         }
@@ -87,16 +103,18 @@ __device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const typename A::T
             const int half = M >> u;
             if (u == 1 && scale) {
                 // last stage of the inverse with the n^-1 factor folded in (ntt.rs:231-235)
+                const typename A::Tw s = w.get(1);
 #pragma unroll
                 for (int i = 0; i < half; i++)
-                    A::gs_last(x[i], x[i + half], w[1], c);
+                    A::gs_last(x[i], x[i + half], s, c);
             } else {
 #pragma unroll
                 for (int b = 0; b < (1 << (u - 1)); b++) {
+                    const typename A::Tw s = w.get((1 << (u - 1)) + b);
 #pragma unroll
                     for (int i = 0; i < half; i++) {
                         const int lo = b * 2 * half + i;
-                        A::gs(x[lo], x[lo + half], w[(1 << (u - 1)) + b], c);
+                        A::gs(x[lo], x[lo + half], s, c);
                     }
                 }
             }
@@ -104,20 +122,18 @@ __device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const typename A::T
     }
 }
 
-// The reference's first sweep accepts any u64 (ntt.rs:125-127).  Residues are the common case,
-// so one max over the high words screens all M values and the per-element reduction runs only
-// in lanes that hold a candidate.
+// The reference's first sweep accepts any u64 (ntt.rs:125-127).  Residues are the common case:
+// each value is screened by its high word alone (one 32-bit compare) and only candidates take
+// the reduction.  Values are tested one by one so that work on the first loaded elements can
+// start while later loads are still in flight.
 template <class A, int M>
 __device__ __forceinline__ void condition_all(uint64_t (&x)[M], const typename A::Ctx& c)
 {
     if constexpr (A::CONDITIONS_INPUT) {
-        uint32_t mx = 0;
+        const uint32_t qh = hi32(A::modulus(c));
 #pragma unroll
-        for (int i = 0; i < M; i++)
-            mx = max(mx, hi32(x[i]));
-        if (mx >= hi32(A::modulus(c))) {
-#pragma unroll
-            for (int i = 0; i < M; i++)
+        for (int i = 0; i < M; i++) {
+            if (hi32(x[i]) >= qh)
                 x[i] = A::condition_input(x[i], c);
         }
     }
@@ -278,7 +294,7 @@ __device__ __forceinline__ void do_round(const PassParams& p, const TileGeom<K1 
         else
             r.load_lds(x, lds);
         if (!(p.flags & PASS_DEBUG_NO_MATH))
-            radix<A, R::KR, FWD>(x, w, c, ROUND_A && (p.flags & PASS_SCALE));
+            radix<A, R::KR, FWD>(x, RegTw<A, R::KR>{w}, c, ROUND_A && (p.flags & PASS_SCALE));
         if (FWD && LAST_OF_PASS && (p.flags & PASS_FINISH))
             finish_all<A, R::M>(x, c);
         if (DST_G)
@@ -330,61 +346,143 @@ __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<
     }
 }
 
-// The 8-stage pass (two radix-16 rounds, one group per thread), written out so that the
-// twiddles of the second round are requested before the workgroup barrier and their latency
-// overlaps the LDS exchange.  In a CONTIG tile the round with 128-byte runs (round A) talks to
-// HBM directly; the other side goes through LDS for 16-byte-per-lane coalescing.
+// Where entry idx = (P16 * 16 + rhigh) * 2^(v-1) + i of the last four stages' twiddles (v = 1..4,
+// the stride-8..1 stages of a transform; P16 counts groups of 16 consecutive rhigh) lives in the
+// regrouped table: inside each group the 16 rhigh values become the fastest index, so the 16
+// lanes that share a sub-transform read 16 consecutive entries.  Stage v occupies
+// [n >> (5 - v), n >> (4 - v)) in both layouts.
+__host__ __device__ inline uint64_t permuted_index(uint64_t idx, uint32_t logn)
+{
+    if (logn < 8 || idx < (1ull << (logn - 4)))
+        return idx;
+    uint32_t top = 63;
+    while (!((idx >> top) & 1))
+        top--;
+    const uint32_t v = top - (logn - 5);            // 1..4
+    const uint64_t base = 1ull << top;
+    const uint64_t off = idx - base;                 // (beta * 16 + rhigh) << (v-1) | i
+    const uint64_t i = off & ((1ull << (v - 1)) - 1);
+    const uint64_t pr = off >> (v - 1);
+    const uint64_t rhigh = pr & 15, beta = pr >> 4;
+    return base + (beta << (v + 3)) + (i << 4) + rhigh;
+}
+
+// The 8-stage pass (two radix-16 rounds, one group per thread).
+//
+// Twiddles: of the two rounds, one needs 16 sets of 15 twiddles per workgroup (one set per
+// 16 lanes) and the other either a single set (STRIDED, round A) or one set per thread (CONTIG,
+// round B, the last four stages of the transform).  The shared sets are fetched once per
+// workgroup -- one 16-byte load per thread -- into a 4 KiB LDS table and read at the point of
+// use; the per-thread sets come from the regrouped table with lane-contiguous loads, requested
+// before the workgroup barrier so their latency overlaps the LDS exchange.
+//
+// Data: in a CONTIG tile the round with 128-byte runs (round A) talks to HBM directly; the
+// other side goes through LDS for 16-byte-per-lane coalescing.
 template <class A, bool FWD, bool CONTIG>
 __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8>& g, const typename A::Ctx& c,
-                                       uint64_t* lds)
+                                       uint64_t* lds, typename A::TwElem* ldstw)
 {
     using RA = Round<A, CONTIG, 4, 4, true>;
     using RB = Round<A, CONTIG, 4, 4, false>;
-    const typename A::TwElem* tw = static_cast<const typename A::TwElem*>(p.tw);
+    using TwElem = typename A::TwElem;
+    const TwElem* tw = static_cast<const TwElem*>(p.tw);
+    const TwElem* twp = static_cast<const TwElem*>(p.tw_perm);
     const RA ra(g, 0);
     const RB rb(g, 0);
-    typename A::Tw w[16];
     uint64_t x[16];
     const bool scale = p.flags & PASS_SCALE;
     const bool math = !(p.flags & PASS_DEBUG_NO_MATH);
+    const bool twl = !(p.flags & PASS_DEBUG_NO_TW);
+
+    // ---- stage the shared twiddle sets: thread t fetches entry j = t & 15 of set t >> 4 ----
+    const uint32_t set = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const uint32_t u = 32 - __clz(j | 1);           // stage of entry j (j = 0 is unused)
+    const uint32_t b = j ? j - (1u << (u - 1)) : 0;
+    // STRIDED: set = rhigh of round B, base (P << 4) + set; CONTIG: set = sigma of round A
+    const uint64_t Pset = CONTIG ? (g.valid(set) ? g.twiddle_base(set) : 1)
+                                 : ((g.twiddle_base(0) << 4) + set);
+    TwElem mine{}, uni{};
+    if (twl) {
+        mine = tw[(Pset << (u - 1)) + b];
+        if (!CONTIG && threadIdx.x < 16)
+            uni = tw[(g.twiddle_base(0) << (u - 1)) + b];
+    }
+    // the single set of STRIDED round A sits after the 16 sets
+    TwElem* const shared_sets = ldstw;
+    TwElem* const uniform_set = ldstw + 256;
+
+    // per-thread twiddles of CONTIG round B: entry (1 << (v-1)) + i <- regrouped table
+    auto load_last = [&](typename A::Tw (&w)[16]) {
+        const uint64_t beta16 = (rb.P >> 4) << 4;   // twiddle base of rhigh = 0 in this sub-transform
+        const uint32_t rhigh = (uint32_t)(rb.P & 15);
+#pragma unroll
+        for (int v = 1; v <= 4; v++) {
+            // original index (beta16 + rhigh) << (v-1) | i  ->  (beta16 << (v-1)) + (i << 4) + rhigh
+            const TwElem* row = twp + (beta16 << (v - 1)) + rhigh;
+#pragma unroll
+            for (int i = 0; i < (1 << (v - 1)); i++)
+                w[(1 << (v - 1)) + i] = A::load(row, i << 4, c);
+        }
+    };
 
     if (FWD) {
-        load_twiddles<A, 4>(w, tw, ra.P, c);
         ra.load_global(x, p, g, c);
-        if (math)
-            radix<A, 4, true>(x, w, c, false);
-        ra.store_lds(x, lds);
-        load_twiddles<A, 4>(w, tw, rb.P, c);
+        shared_sets[threadIdx.x] = mine;
+        if (!CONTIG && threadIdx.x < 16)
+            uniform_set[threadIdx.x] = uni;
         __syncthreads();
-        rb.load_lds(x, lds);
+        // round A: STRIDED reads the single set, CONTIG the set of its sub-transform
         if (math)
-            radix<A, 4, true>(x, w, c, false);
-        if (p.flags & PASS_FINISH)
-            finish_all<A, 16>(x, c);
+            radix<A, 4, true>(x, LdsTw<A>{CONTIG ? shared_sets + (ra.sigma << 4) : uniform_set, c}, c, false);
+        ra.store_lds(x, lds);
         if (CONTIG) {
-            rb.store_lds(x, lds);
+            typename A::Tw w[16];
+            if (twl)
+                load_last(w);
+            __syncthreads();
+            rb.load_lds(x, lds);
+            if (math)
+                radix<A, 4, true>(x, RegTw<A, 4>{w}, c, false);
+            if (p.flags & PASS_FINISH)
+                finish_all<A, 16>(x, c);
+            rb.store_lds(x, lds); // the addresses this thread just read: no hazard with other threads
             __syncthreads();
             copy_contig<A, 8, false>(p, g, c, lds);
         } else {
+            __syncthreads();
+            rb.load_lds(x, lds);
+            if (math)
+                radix<A, 4, true>(x, LdsTw<A>{shared_sets + ((threadIdx.x >> 4) << 4), c}, c, false);
+            if (p.flags & PASS_FINISH)
+                finish_all<A, 16>(x, c);
             rb.store_global(x, p, g);
         }
     } else {
-        load_twiddles<A, 4>(w, tw, rb.P, c);
         if (CONTIG) {
+            typename A::Tw w[16];
+            if (twl)
+                load_last(w);
             copy_contig<A, 8, true>(p, g, c, lds);
+            shared_sets[threadIdx.x] = mine;
             __syncthreads();
             rb.load_lds(x, lds);
+            if (math)
+                radix<A, 4, false>(x, RegTw<A, 4>{w}, c, false);
+            rb.store_lds(x, lds);
         } else {
             rb.load_global(x, p, g, c);
+            shared_sets[threadIdx.x] = mine;
+            if (threadIdx.x < 16)
+                uniform_set[threadIdx.x] = uni;
+            __syncthreads();
+            if (math)
+                radix<A, 4, false>(x, LdsTw<A>{shared_sets + ((threadIdx.x >> 4) << 4), c}, c, false);
+            rb.store_lds(x, lds);
         }
-        if (math)
-            radix<A, 4, false>(x, w, c, false);
-        rb.store_lds(x, lds);
-        load_twiddles<A, 4>(w, tw, ra.P, c);
         __syncthreads();
         ra.load_lds(x, lds);
         if (math)
-            radix<A, 4, false>(x, w, c, scale);
+            radix<A, 4, false>(x, LdsTw<A>{CONTIG ? shared_sets + (ra.sigma << 4) : uniform_set, c}, c, scale);
         ra.store_global(x, p, g);
     }
 }
@@ -397,7 +495,8 @@ __global__ __launch_bounds__(THREADS, 4) void pass_kernel(PassParams p, typename
     const TileGeom<K> g(p, blockIdx.x);
 
     if constexpr (K1 == 4 && K2 == 4) {
-        pass_8<A, FWD, CONTIG>(p, g, c, lds);
+        __shared__ __attribute__((aligned(16))) typename A::TwElem ldstw[256 + 16];
+        pass_8<A, FWD, CONTIG>(p, g, c, lds, ldstw);
     } else if constexpr (CONTIG) {
         copy_contig<A, K, true>(p, g, c, lds);
         __syncthreads();

@@ -51,7 +51,8 @@ struct nttx_plan {
     std::vector<uint64_t> h_fwd, h_inv;       // tables as the caller passed them
     std::vector<nttx::TwPair> h_fwd2, h_inv2; // SHOUP61: plain twiddle + quotient
     std::vector<int> devices;
-    std::vector<void*> d_fwd, d_inv; // per device
+    std::vector<void*> d_fwd, d_inv;           // per device: tables in the reference's index order
+    std::vector<void*> d_fwd_perm, d_inv_perm; // per device: last four stages regrouped (permuted_index)
     std::vector<PassDesc> passes;        // forward order
 };
 
@@ -147,6 +148,7 @@ int enqueue_passes(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch
         PassParams p;
         p.data = dptr;
         p.tw = fwd ? plan->d_fwd[slot] : plan->d_inv[slot];
+        p.tw_perm = fwd ? plan->d_fwd_perm[slot] : plan->d_inv_perm[slot];
         p.nblocks_total = (uint64_t)batch << d.s0;
         p.logB = plan->logn - d.s0;
         p.s0 = d.s0;
@@ -160,6 +162,9 @@ int enqueue_passes(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch
         static const bool no_math = std::getenv("NTTX_DEBUG_NO_MATH") != nullptr;
         if (no_math)
             p.flags |= PASS_DEBUG_NO_MATH;
+        static const bool no_tw = std::getenv("NTTX_DEBUG_NO_TW") != nullptr;
+        if (no_tw)
+            p.flags |= PASS_DEBUG_NO_TW;
         hipError_t e;
         switch (plan->policy) {
         case nttx_plan::GOLDILOCKS: e = launch_dir<Goldilocks>(fwd, d, p, plan->gctx, (unsigned)tiles, stream); break;
@@ -315,17 +320,32 @@ int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
     int prev = 0;
     (void)hipGetDevice(&prev);
     const bool pairs = plan->policy == nttx_plan::SHOUP61;
-    const size_t bytes = plan->n * (pairs ? sizeof(nttx::TwPair) : sizeof(uint64_t));
-    const void* src_fwd = pairs ? (const void*)plan->h_fwd2.data() : (const void*)plan->h_fwd.data();
-    const void* src_inv = pairs ? (const void*)plan->h_inv2.data() : (const void*)plan->h_inv.data();
-    plan->d_fwd.assign(plan->devices.size(), nullptr);
-    plan->d_inv.assign(plan->devices.size(), nullptr);
-    for (size_t i = 0; i < plan->devices.size(); i++) {
+    const size_t esz = pairs ? sizeof(nttx::TwPair) : sizeof(uint64_t);
+    const size_t bytes = plan->n * esz;
+    const char* src_fwd = pairs ? (const char*)plan->h_fwd2.data() : (const char*)plan->h_fwd.data();
+    const char* src_inv = pairs ? (const char*)plan->h_inv2.data() : (const char*)plan->h_inv.data();
+    // regrouped copies for the pass that holds the last four stages
+    std::vector<char> perm_fwd(bytes), perm_inv(bytes);
+    for (uint64_t i = 0; i < plan->n; i++) {
+        const uint64_t j = nttx::permuted_index(i, plan->logn);
+        std::memcpy(&perm_fwd[j * esz], src_fwd + i * esz, esz);
+        std::memcpy(&perm_inv[j * esz], src_inv + i * esz, esz);
+    }
+    const size_t nd = plan->devices.size();
+    plan->d_fwd.assign(nd, nullptr);
+    plan->d_inv.assign(nd, nullptr);
+    plan->d_fwd_perm.assign(nd, nullptr);
+    plan->d_inv_perm.assign(nd, nullptr);
+    for (size_t i = 0; i < nd; i++) {
         HIP_TRY(hipSetDevice(plan->devices[i]));
         HIP_TRY(hipMalloc(&plan->d_fwd[i], bytes));
         HIP_TRY(hipMalloc(&plan->d_inv[i], bytes));
+        HIP_TRY(hipMalloc(&plan->d_fwd_perm[i], bytes));
+        HIP_TRY(hipMalloc(&plan->d_inv_perm[i], bytes));
         HIP_TRY(hipMemcpy(plan->d_fwd[i], src_fwd, bytes, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(plan->d_inv[i], src_inv, bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(plan->d_fwd_perm[i], perm_fwd.data(), bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(plan->d_inv_perm[i], perm_inv.data(), bytes, hipMemcpyHostToDevice));
     }
     (void)hipSetDevice(prev);
     return NTTX_OK;
@@ -462,6 +482,10 @@ void nttx_plan_destroy(nttx_plan* plan)
             (void)hipFree(plan->d_fwd[i]);
         if (i < plan->d_inv.size() && plan->d_inv[i])
             (void)hipFree(plan->d_inv[i]);
+        if (i < plan->d_fwd_perm.size() && plan->d_fwd_perm[i])
+            (void)hipFree(plan->d_fwd_perm[i]);
+        if (i < plan->d_inv_perm.size() && plan->d_inv_perm[i])
+            (void)hipFree(plan->d_inv_perm[i]);
     }
     (void)hipSetDevice(prev);
     delete plan;
