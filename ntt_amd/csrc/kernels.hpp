@@ -130,7 +130,8 @@ template <class A, int M>
 __device__ __forceinline__ void condition_all(uint64_t (&x)[M], const typename A::Ctx& c)
 {
     if constexpr (A::CONDITIONS_INPUT) {
-        const uint32_t qh = hi32(A::modulus(c));
+        uint32_t qh = hi32(A::modulus(c));
+        asm volatile("" : "+s"(qh)); // keep the screen a 32-bit compare (hipcc widens it otherwise)
 #pragma unroll
         for (int i = 0; i < M; i++) {
             if (hi32(x[i]) >= qh)
@@ -401,12 +402,8 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8>& g
     // STRIDED: set = rhigh of round B, base (P << 4) + set; CONTIG: set = sigma of round A
     const uint64_t Pset = CONTIG ? (g.valid(set) ? g.twiddle_base(set) : 1)
                                  : ((g.twiddle_base(0) << 4) + set);
-    TwElem mine{}, uni{};
-    if (twl) {
-        mine = tw[(Pset << (u - 1)) + b];
-        if (!CONTIG && threadIdx.x < 16)
-            uni = tw[(g.twiddle_base(0) << (u - 1)) + b];
-    }
+    const TwElem mine = tw[(Pset << (u - 1)) + b];
+    const TwElem uni = tw[(g.twiddle_base(0) << (u - 1)) + b]; // used by threads 0..15 of a STRIDED tile
     // the single set of STRIDED round A sits after the 16 sets
     TwElem* const shared_sets = ldstw;
     TwElem* const uniform_set = ldstw + 256;
