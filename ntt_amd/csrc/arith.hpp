@@ -142,6 +142,7 @@ struct Shoup61 {
     using Ctx = Shoup61Ctx;
     using TwElem = TwPair;
     static constexpr bool CONDITIONS_INPUT = true;
+    static constexpr bool DEFERRED_CHECK = false;
     static NTTX_HD uint64_t modulus(const Ctx& c) { return c.q; }
     struct Tw {
         uint32_t w0, w1, v0, v1;
@@ -258,6 +259,7 @@ struct Mont {
     using Ctx = MontCtx;
     using TwElem = uint64_t;
     static constexpr bool CONDITIONS_INPUT = true;
+    static constexpr bool DEFERRED_CHECK = false;
     static NTTX_HD uint64_t modulus(const Ctx& c) { return c.q; }
     struct Tw {
         uint64_t w;
@@ -342,72 +344,326 @@ struct Goldilocks {
         uint64_t w;
     };
     static constexpr uint64_t Q = 0xffffffff00000001ull;
+    static constexpr uint64_t EPS = 0xffffffffull; // 2^64 - q
 
     static NTTX_HD Tw load(const TwElem* __restrict__ t, uint64_t i, const Ctx&) { return Tw{t[i]}; }
 
-    // mul_reduce (ntt_goldilock.rs:183-190) with reduce_159 (:63-79): canonical a*b mod q
-    // for any u64 a, b.
-    static NTTX_HD uint64_t mul(uint64_t a, uint64_t b, const Ctx&)
+    // ---- the reference's rules, statement by statement ---------------------------------------
+    // mul_reduce (ntt_goldilock.rs:183-190) with reduce_159 (:63-79).  Whatever a and b are, the
+    // result is the canonical residue a*b mod q: low_2 + product stays below 2q, so the single
+    // conditional subtraction always lands in [0, q).
+    static NTTX_HD uint64_t mul_strict(uint64_t a, uint64_t b)
     {
         uint64_t hi, lo;
         mul_wide(a, b, hi, lo);
-        const uint64_t high = hi >> 32;
-        const uint64_t middle = hi & 0xffffffffull;
+        // reduce_159(low = lo, middle = hi & 0xffffffff, high = hi >> 32)
+        const uint64_t high = hi32(hi);
         uint64_t low_2 = lo - high;
         if (lo < high)
             low_2 += Q;
-        const uint64_t product = (middle << 32) - middle;
+        const uint64_t product = (uint64_t)lo32(hi) * 0xffffffffull; // (middle << 32) - middle
         uint64_t res = low_2 + product;
         if (res < product || res >= Q)
             res -= Q;
         return res;
     }
-
     // ntt_goldilock.rs:104-112: carry -> -q, else strictly-greater -> -q (a sum of exactly q stays)
-    static NTTX_HD uint64_t add(uint64_t u, uint64_t v, const Ctx&)
+    static NTTX_HD uint64_t add_strict(uint64_t u, uint64_t v)
     {
         const uint64_t s = u + v;
         const bool carry = s < u;
         return (carry || s > Q) ? s - Q : s;
     }
-
     // ntt_goldilock.rs:115-120: borrow -> +q, then % q
-    static NTTX_HD uint64_t sub_ct(uint64_t u, uint64_t v, const Ctx&)
+    static NTTX_HD uint64_t sub_ct_strict(uint64_t u, uint64_t v)
     {
         uint64_t d = u - v;
         if (u < v)
             d += Q;
         return (d >= Q) ? d - Q : d;
     }
-
     // ntt_goldilock.rs:162-165: borrow -> +q, no further reduction
-    static NTTX_HD uint64_t sub_gs(uint64_t u, uint64_t v, const Ctx&)
+    static NTTX_HD uint64_t sub_gs_strict(uint64_t u, uint64_t v)
     {
         const uint64_t d = u - v;
         return (u < v) ? d + Q : d;
     }
 
+    // ---- the same results in fewer instructions -----------------------------------------------
+    // Each fast routine applies only the correction its carry / borrow asks for (adding
+    // 2^32 - 1 = 2^64 - q, i.e. subtracting q mod 2^64) and hands back the high word of its
+    // result.  It can differ from the strict rule only when the strict rule's remaining test
+    // (a compare against q without carry) fires, and then that high word is 0xffffffff.  The
+    // butterflies OR those words' all-ones test into one rarely-taken branch that redoes the
+    // butterfly with the strict routines, so outputs are bit-identical for every input while the
+    // common path has no 64-bit compares or selects.
+    //
+    // The device forms are written out because hipcc cannot keep a carry in VCC across C++
+    // statements; each has its C++ meaning beside it, which is what the host build compiles.
+    // s_nop 1 = the two wait states gfx950 needs between a VALU write of VCC / an SGPR and a
+    // VALU read of it as carry-in or select mask.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+    using Carry = uint64_t; // wave lane mask in an SGPR pair
+#else
+    using Carry = uint32_t; // 0 or 1
+#endif
+
+    // (hi32(p), 0), (lo32(p), 0), (lo32(p), lo32(r)) as aligned register pairs, one instruction each
+    static NTTX_HD uint64_t zhi(uint64_t p)
+    {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+        uint64_t d;
+        asm("v_pk_mov_b32 %0, %1, 0 op_sel:[1,0]" : "=v"(d) : "v"(p));
+        return d;
+#else
+        return p >> 32;
+#endif
+    }
+    static NTTX_HD uint64_t zlo(uint64_t p)
+    {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+        uint64_t d;
+        asm("v_pk_mov_b32 %0, %1, 0 op_sel:[0,0]" : "=v"(d) : "v"(p));
+        return d;
+#else
+        return p & 0xffffffffull;
+#endif
+    }
+    static NTTX_HD uint64_t packlo(uint64_t p, uint64_t r)
+    {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+        uint64_t d;
+        asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(d) : "v"(p), "v"(r));
+        return d;
+#else
+        return (r << 32) | (p & 0xffffffffull);
+#endif
+    }
+
+    // x + m * (2^32 - 1) mod 2^64 and its carry
+    static NTTX_HD uint64_t mad_eps(uint32_t m, uint64_t x, Carry& carry)
+    {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+        uint64_t d;
+        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(d), "=s"(carry) : "v"(m), "v"(x));
+        return d;
+#else
+        const uint64_t p = (uint64_t)m * EPS, d = x + p;
+        carry = d < p;
+        return d;
+#endif
+    }
+
+    // Canonical a*b mod q unless the returned word `top` (the result's high half) is 0xffffffff.
+    //
+    // With the 128-bit product as 32-bit limbs x0..x3: a*b = lo + 2^64*x2 + 2^96*x3 with
+    // lo = x0 + 2^32*x1, and 2^64 = eps, 2^96 = -1 (mod q), so a*b = V := lo + x2*eps - x3.
+    // X = lo + x2*eps is one multiply-add with carry c.  If c is set V lies in [q, 2q), and
+    // V - q = X - x3 - c + c*2^32 (mod 2^64) is exact and canonical.  If not, V < 2^64: the
+    // wrapped X - x3 is V when 0 <= V, canonical unless V >= q (high word all ones), and
+    // V + 2^64 > 2^64 - 2^32 (high word all ones again) when V < 0.
+    static NTTX_HD uint64_t mul_fast(uint64_t a, uint64_t b, uint32_t& top)
+    {
+        const uint32_t a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
+        const uint64_t p0 = mul32(a0, b0);
+        const uint64_t p1 = mad32(a1, b0, zhi(p0));
+        const uint64_t p2 = mad32(a0, b1, zlo(p1));  // lo32 = x1
+        const uint64_t h = mad32(a1, b1, zhi(p1));   // + hi32(p2) = (x2, x3)
+        const uint64_t lo = packlo(p0, p2);
+        uint32_t x2, x3;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+        asm("v_add_co_u32 %0, vcc, %2, %4\n\t"
+            "s_nop 1\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %3, vcc"
+            : "=&v"(x2), "=&v"(x3)
+            : "v"(lo32(h)), "v"(hi32(h)), "v"(hi32(p2))
+            : "vcc");
+#else
+        {
+            const uint64_t hh = h + hi32(p2);
+            x2 = lo32(hh);
+            x3 = hi32(hh);
+        }
+#endif
+        Carry c;
+        const uint64_t x = mad_eps(x2, lo, c);
+        uint32_t tl, th;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+        asm("s_nop 1\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %3, %5\n\t" // th = xh + c
+            "v_subb_co_u32 %0, vcc, %2, %4, %5\n\t" // tl = xl - x3 - c, vcc = borrow
+            "s_nop 1\n\t"
+            "v_subbrev_co_u32 %1, vcc, 0, %1, vcc" // th -= borrow
+            : "=&v"(tl), "=&v"(th)
+            : "v"(lo32(x)), "v"(hi32(x)), "v"(x3), "s"(c)
+            : "vcc");
+#else
+        {
+            const uint64_t t = x - x3 - c + ((uint64_t)c << 32);
+            tl = lo32(t);
+            th = hi32(t);
+        }
+#endif
+        top = th;
+        return pack64(tl, th);
+    }
+
+    // u + v mod 2^64, minus q if that carried.  Differs from add_strict only when the sum did not
+    // carry yet exceeds q, and then `top`, its high word, is 0xffffffff.
+    static NTTX_HD uint64_t add_fast(uint64_t u, uint64_t v, uint32_t& top)
+    {
+        uint32_t sl, sh;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+        uint32_t e;
+        asm("v_add_co_u32 %0, vcc, %3, %5\n\t"
+            "s_nop 1\n\t"
+            "v_addc_co_u32 %1, vcc, %4, %6, vcc\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+            "v_add_co_u32 %0, vcc, %0, %2\n\t"
+            "s_nop 1\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "=&v"(sl), "=&v"(sh), "=&v"(e)
+            : "v"(lo32(u)), "v"(hi32(u)), "v"(lo32(v)), "v"(hi32(v))
+            : "vcc");
+#else
+        {
+            uint64_t s = u + v;
+            if (s < u)
+                s += EPS;
+            sl = lo32(s);
+            sh = hi32(s);
+        }
+#endif
+        top = sh;
+        return pack64(sl, sh);
+    }
+
+    // u - v mod 2^64, plus q if that borrowed: sub_gs_strict exactly; sub_ct_strict unless the
+    // result is >= q, and then `top`, its high word, is 0xffffffff.
+    static NTTX_HD uint64_t sub_fast(uint64_t u, uint64_t v, uint32_t& top)
+    {
+        uint32_t dl, dh;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+        uint32_t e;
+        asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+            "s_nop 1\n\t"
+            "v_subb_co_u32 %1, vcc, %4, %6, vcc\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+            "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+            "s_nop 1\n\t"
+            "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+            : "=&v"(dl), "=&v"(dh), "=&v"(e)
+            : "v"(lo32(u)), "v"(hi32(u)), "v"(lo32(v)), "v"(hi32(v))
+            : "vcc");
+#else
+        {
+            uint64_t d = u - v;
+            if (u < v)
+                d -= EPS;
+            dl = lo32(d);
+            dh = hi32(d);
+        }
+#endif
+        top = dh;
+        return pack64(dl, dh);
+    }
+
+    static NTTX_HD uint32_t max3(uint32_t x, uint32_t y, uint32_t z)
+    {
+        const uint32_t m = x > y ? x : y;
+        return m > z ? m : z;
+    }
+
+    static NTTX_HD uint64_t mul(uint64_t a, uint64_t b, const Ctx&) { return mul_strict(a, b); }
+
+    // Butterflies in two forms.  *_fast returns a word that is 0xffffffff whenever its outputs may
+    // differ from *_strict (the reference's statements); callers take the maximum of those words
+    // over a group of independent butterflies and redo the group strictly if it is all ones, so a
+    // group costs one branch and its butterflies can be interleaved.
+    static constexpr bool DEFERRED_CHECK = true;
+    static constexpr uint32_t SUSPECT = 0xffffffffu;
+
+    // ntt_goldilock.rs:98-121
+    static NTTX_HD uint32_t ct_fast(uint64_t& a, uint64_t& b, const Tw& s, const Ctx&)
+    {
+        const uint64_t u = a;
+        uint32_t t0, t1, t2;
+        const uint64_t v = mul_fast(b, s.w, t0);
+        a = add_fast(u, v, t1);
+        b = sub_fast(u, v, t2);
+        return max3(t0, t1, t2);
+    }
+    static NTTX_HD void ct_strict(uint64_t& a, uint64_t& b, const Tw& s, const Ctx&)
+    {
+        const uint64_t u = a, v = mul_strict(b, s.w);
+        a = add_strict(u, v);
+        b = sub_ct_strict(u, v);
+    }
+
+    // ntt_goldilock.rs:152-166
+    static NTTX_HD uint32_t gs_fast(uint64_t& a, uint64_t& b, const Tw& s, const Ctx&)
+    {
+        const uint64_t u = a, v = b;
+        uint32_t t0, t1, t2;
+        a = add_fast(u, v, t0);
+        b = mul_fast(sub_fast(u, v, t2), s.w, t1);
+        return t0 > t1 ? t0 : t1;
+    }
+    static NTTX_HD void gs_strict(uint64_t& a, uint64_t& b, const Tw& s, const Ctx&)
+    {
+        const uint64_t u = a, v = b;
+        a = add_strict(u, v);
+        b = mul_strict(sub_gs_strict(u, v), s.w);
+    }
+
+    // last stage + mul_reduce(., n_inv) (ntt_goldilock.rs:177-179): both products are canonical.
+    // `sf` = s * n_inv, computed once per twiddle by the caller (scaled()).
+    static NTTX_HD Tw scaled(const Tw& s, const Ctx& c) { return Tw{mul_strict(s.w, c.n_inv)}; }
+    static NTTX_HD uint32_t gs_last_fast(uint64_t& a, uint64_t& b, const Tw& sf, const Ctx& c)
+    {
+        const uint64_t u = a, v = b;
+        uint32_t t0, t1, t2, t3;
+        a = mul_fast(add_fast(u, v, t0), c.n_inv, t1);
+        b = mul_fast(sub_fast(u, v, t3), sf.w, t2);
+        return max3(t0, t1, t2);
+    }
+    static NTTX_HD void gs_last_strict(uint64_t& a, uint64_t& b, const Tw& sf, const Ctx& c)
+    {
+        const uint64_t u = a, v = b;
+        a = mul_strict(add_strict(u, v), c.n_inv);
+        b = mul_strict(sub_gs_strict(u, v), sf.w);
+    }
+
+    // self-contained butterflies (one check each)
     static NTTX_HD void ct(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
     {
-        const uint64_t u = a, v = mul(b, s.w, c);
-        a = add(u, v, c);
-        b = sub_ct(u, v, c);
+        const uint64_t u = a, y = b;
+        if (__builtin_expect(ct_fast(a, b, s, c) == SUSPECT, 0)) {
+            a = u;
+            b = y;
+            ct_strict(a, b, s, c);
+        }
     }
-
     static NTTX_HD void gs(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
     {
-        const uint64_t u = a, v = b;
-        a = add(u, v, c);
-        b = mul(sub_gs(u, v, c), s.w, c);
+        const uint64_t u = a, y = b;
+        if (__builtin_expect(gs_fast(a, b, s, c) == SUSPECT, 0)) {
+            a = u;
+            b = y;
+            gs_strict(a, b, s, c);
+        }
     }
-
-    // last stage + mul_reduce(., n_inv) (ntt_goldilock.rs:177-179): both products are canonical
     static NTTX_HD void gs_last(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
     {
-        const uint64_t u = a, v = b;
-        const uint64_t sf = mul(s.w, c.n_inv, c);
-        a = mul(add(u, v, c), c.n_inv, c);
-        b = mul(sub_gs(u, v, c), sf, c);
+        const uint64_t u = a, y = b;
+        const Tw sf = scaled(s, c);
+        if (__builtin_expect(gs_last_fast(a, b, sf, c) == SUSPECT, 0)) {
+            a = u;
+            b = y;
+            gs_last_strict(a, b, sf, c);
+        }
     }
 
     static NTTX_HD uint64_t condition_input(uint64_t x, const Ctx&) { return x; }

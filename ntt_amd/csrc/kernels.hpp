@@ -79,11 +79,61 @@ struct LdsTw { // one 16-entry set staged in LDS, read where it is used
 // K butterfly stages on 2^K registers.  Register i holds sub-transform element i (stride
 // handled by the caller); stage u = 1..K pairs i with i + 2^(K-u) and uses twiddle entry
 // (1 << (u-1)) + (i >> (K-u+1)) of the source.
+//
+// A policy with DEFERRED_CHECK computes a stage with its fast butterflies, which report whether
+// any of them may deviate from the strict rules; the stage is then redone strictly from its
+// inputs.  One branch per stage keeps the 2^(K-1) independent butterflies interleavable.
 template <class A, int K, bool FWD, class Src>
 __device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const Src& w, const typename A::Ctx& c, bool scale)
 {
     constexpr int M = 1 << K;
-    if (FWD) {
+    if constexpr (A::DEFERRED_CHECK) {
+        uint64_t in[M];
+#pragma unroll
+        for (int step = 1; step <= K; step++) {
+            const int u = FWD ? step : K + 1 - step;
+            const int half = M >> u;
+            const bool last = !FWD && u == 1 && scale;
+#pragma unroll
+            for (int i = 0; i < M; i++)
+                in[i] = x[i];
+            uint32_t suspect = 0;
+#pragma unroll
+            for (int b = 0; b < (1 << (u - 1)); b++) {
+                typename A::Tw s = w.get((1 << (u - 1)) + b);
+                if (last)
+                    s = A::scaled(s, c);
+#pragma unroll
+                for (int i = 0; i < half; i++) {
+                    const int lo = b * 2 * half + i;
+                    const uint32_t t = FWD    ? A::ct_fast(x[lo], x[lo + half], s, c)
+                                       : last ? A::gs_last_fast(x[lo], x[lo + half], s, c)
+                                              : A::gs_fast(x[lo], x[lo + half], s, c);
+                    suspect = t > suspect ? t : suspect;
+                }
+            }
+            if (__builtin_expect(suspect == A::SUSPECT, 0)) {
+#pragma unroll
+                for (int b = 0; b < (1 << (u - 1)); b++) {
+                    typename A::Tw s = w.get((1 << (u - 1)) + b);
+                    if (last)
+                        s = A::scaled(s, c);
+#pragma unroll
+                    for (int i = 0; i < half; i++) {
+                        const int lo = b * 2 * half + i;
+                        x[lo] = in[lo];
+                        x[lo + half] = in[lo + half];
+                        if (FWD)
+                            A::ct_strict(x[lo], x[lo + half], s, c);
+                        else if (last)
+                            A::gs_last_strict(x[lo], x[lo + half], s, c);
+                        else
+                            A::gs_strict(x[lo], x[lo + half], s, c);
+                    }
+                }
+            }
+        }
+    } else if (FWD) {
 #pragma unroll
         for (int u = 1; u <= K; u++) {
             const int half = M >> u;
@@ -402,11 +452,15 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8>& g
     // STRIDED: set = rhigh of round B, base (P << 4) + set; CONTIG: set = sigma of round A
     const uint64_t Pset = CONTIG ? (g.valid(set) ? g.twiddle_base(set) : 1)
                                  : ((g.twiddle_base(0) << 4) + set);
-    const TwElem mine = tw[(Pset << (u - 1)) + b];
-    const TwElem uni = tw[(g.twiddle_base(0) << (u - 1)) + b]; // used by threads 0..15 of a STRIDED tile
+    // moved as raw dwords: a struct temporary held across the data loads ends up on the stack
+    using Raw = __attribute__((ext_vector_type(sizeof(TwElem) / 4))) uint32_t;
+    const Raw mine = *reinterpret_cast<const Raw*>(tw + ((Pset << (u - 1)) + b));
+    const Raw uni = *reinterpret_cast<const Raw*>(tw + ((g.twiddle_base(0) << (u - 1)) + b)); // threads 0..15, STRIDED
     // the single set of STRIDED round A sits after the 16 sets
     TwElem* const shared_sets = ldstw;
     TwElem* const uniform_set = ldstw + 256;
+    Raw* const shared_raw = reinterpret_cast<Raw*>(shared_sets);
+    Raw* const uniform_raw = reinterpret_cast<Raw*>(uniform_set);
 
     // per-thread twiddles of CONTIG round B: entry (1 << (v-1)) + i <- regrouped table
     auto load_last = [&](typename A::Tw (&w)[16]) {
@@ -424,9 +478,9 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8>& g
 
     if (FWD) {
         ra.load_global(x, p, g, c);
-        shared_sets[threadIdx.x] = mine;
+        shared_raw[threadIdx.x] = mine;
         if (!CONTIG && threadIdx.x < 16)
-            uniform_set[threadIdx.x] = uni;
+            uniform_raw[threadIdx.x] = uni;
         __syncthreads();
         // round A: STRIDED reads the single set, CONTIG the set of its sub-transform
         if (math)
@@ -460,7 +514,7 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8>& g
             if (twl)
                 load_last(w);
             copy_contig<A, 8, true>(p, g, c, lds);
-            shared_sets[threadIdx.x] = mine;
+            shared_raw[threadIdx.x] = mine;
             __syncthreads();
             rb.load_lds(x, lds);
             if (math)
@@ -468,9 +522,9 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8>& g
             rb.store_lds(x, lds);
         } else {
             rb.load_global(x, p, g, c);
-            shared_sets[threadIdx.x] = mine;
+            shared_raw[threadIdx.x] = mine;
             if (threadIdx.x < 16)
-                uniform_set[threadIdx.x] = uni;
+                uniform_raw[threadIdx.x] = uni;
             __syncthreads();
             if (math)
                 radix<A, 4, false>(x, LdsTw<A>{shared_sets + ((threadIdx.x >> 4) << 4), c}, c, false);

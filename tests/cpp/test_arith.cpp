@@ -158,17 +158,50 @@ static void transform_tests(uint64_t q, uint64_t psi, size_t n)
 static void goldilocks_tests()
 {
     const uint64_t q = Goldilocks::Q;
-    GoldilocksCtx c{0};
+    GoldilocksCtx c{0x1234567812345678ull % q};
     std::mt19937_64 rng(5);
-    const uint64_t v[] = {0, 1, q - 1, q, q + 1, ~0ull, 0xffffffffull, 0x100000000ull};
-    for (int it = 0; it < 100000; it++) {
-        uint64_t a = it % 4 == 0 ? v[(it / 4) % 8] : rng(), b = it % 8 == 1 ? v[(it / 8) % 8] : rng();
-        CHECK(Goldilocks::mul(a, b, c) == mulmod(a % q, b % q, q));
+    // values where a carry, a borrow or a compare against q is on the edge
+    std::vector<uint64_t> edge = {0, 1, 2, q - 2, q - 1, q, q + 1, q + 2, ~0ull, ~0ull - 1, 0xffffffffull, 0xfffffffeull,
+                                  0x100000000ull, 0x100000001ull, 0xffffffff00000000ull, 0xfffffffeffffffffull,
+                                  0xfffffffe00000001ull, 0x00000001ffffffffull, 0x8000000000000000ull, 0x7fffffff80000001ull};
+    auto pick = [&](int it, int salt) -> uint64_t {
+        switch ((it + salt) % 4) {
+        case 0: return edge[rng() % edge.size()];
+        case 1: return edge[rng() % edge.size()] + (int64_t)(rng() % 5) - 2;
+        case 2: return (rng() % 3 == 0) ? (rng() & 0xffffffffull) : (rng() | 0xffffffff00000000ull);
+        default: return rng();
+        }
+    };
+    for (int it = 0; it < 400000; it++) {
+        const uint64_t a = pick(it, 0), b = pick(it / 4, 1), w = pick(it / 16, 2);
+        CHECK(Goldilocks::mul_strict(a, b) == mulmod(a % q, b % q, q));
+        uint32_t top;
+        const uint64_t m = Goldilocks::mul_fast(a, b, top);
+        CHECK(top == (uint32_t)(m >> 32));
+        CHECK(m == Goldilocks::mul_strict(a, b) || top == 0xffffffffu);
+        const uint64_t s = Goldilocks::add_fast(a, b, top);
+        CHECK(s == Goldilocks::add_strict(a, b) || top == 0xffffffffu);
+        const uint64_t d = Goldilocks::sub_fast(a, b, top);
+        CHECK(d == Goldilocks::sub_gs_strict(a, b));
+        CHECK(d == Goldilocks::sub_ct_strict(a, b) || top == 0xffffffffu);
+        // whole butterflies against the reference's statements
+        Goldilocks::Tw tw{w};
+        uint64_t x = a, y = b;
+        Goldilocks::ct(x, y, tw, c);
+        uint64_t v = Goldilocks::mul_strict(b, w);
+        CHECK(x == Goldilocks::add_strict(a, v) && y == Goldilocks::sub_ct_strict(a, v));
+        x = a; y = b;
+        Goldilocks::gs(x, y, tw, c);
+        CHECK(x == Goldilocks::add_strict(a, b) && y == Goldilocks::mul_strict(Goldilocks::sub_gs_strict(a, b), w));
+        x = a; y = b;
+        Goldilocks::gs_last(x, y, tw, c);
+        CHECK(x == Goldilocks::mul_strict(Goldilocks::add_strict(a, b), c.n_inv));
+        CHECK(y == Goldilocks::mul_strict(Goldilocks::sub_gs_strict(a, b), Goldilocks::mul_strict(w, c.n_inv)));
     }
-    CHECK(Goldilocks::add(q - 5, 5, c) == q);      // ntt_goldilock.rs:107: a sum of exactly q stays q
-    CHECK(Goldilocks::add(q - 5, 6, c) == 1);
-    CHECK(Goldilocks::sub_ct(q, 0, c) == 0);        // :120
-    CHECK(Goldilocks::sub_gs(q, 0, c) == q);        // :162-165
+    CHECK(Goldilocks::add_strict(q - 5, 5) == q);  // ntt_goldilock.rs:107: a sum of exactly q stays q
+    CHECK(Goldilocks::add_strict(q - 5, 6) == 1);
+    CHECK(Goldilocks::sub_ct_strict(q, 0) == 0);    // :120
+    CHECK(Goldilocks::sub_gs_strict(q, 0) == q);    // :162-165
 }
 
 int main()

@@ -199,6 +199,33 @@ def test_goldilocks_any_u64_input(amd):
         assert np.array_equal(a, w), fn
 
 
+@pytest.mark.parametrize("logn", [4, 8, 12, 16])
+def test_goldilocks_edge_dense_inputs(amd, logn):
+    """Inputs packed with values on the edges of the carry / borrow / compare-with-q rules
+    (ntt_goldilock.rs:63-79, 104-120, 162-165), so that the kernels' strict re-computation of a
+    stage runs in most workgroups, alone and mixed with ordinary residues."""
+    n = 1 << logn
+    rng = np.random.default_rng(logn)
+    edges = np.array([0, 1, 2, QGL - 2, QGL - 1, QGL, QGL + 1, 2**64 - 1, 2**64 - 2, 0xFFFFFFFF, 0xFFFFFFFE,
+                      1 << 32, (1 << 32) + 1, 0xFFFFFFFF00000000, 0xFFFFFFFEFFFFFFFF, 0xFFFFFFFE00000001,
+                      0x1FFFFFFFF, 1 << 63], dtype=np.uint64)
+    psi = psigl_for(n)
+    gpu, ref = amd.TableGoldilock.from_root(psi, n), orc.TableGoldilock.from_root(psi, n)
+    batch = 8
+    for density in (1.0, 0.25, 0.01):
+        raw = rng.integers(0, QGL, batch * n, dtype=np.uint64)
+        pick = rng.random(batch * n) < density
+        raw[pick] = edges[rng.integers(0, len(edges), int(pick.sum()))]
+        hi_ones = rng.random(batch * n) < density / 4      # arbitrary values with an all-ones high word
+        raw[hi_ones] |= np.uint64(0xFFFFFFFF00000000)
+        for fn in ("forward_inplace", "backward_inplace"):
+            a, w = raw.copy(), raw.copy()
+            getattr(gpu, fn + "_batch")(a, batch)
+            for b in range(batch):
+                getattr(ref, fn)(w[b * n:(b + 1) * n])
+            assert np.array_equal(a, w), (fn, density)
+
+
 def test_goldilocks_forward_emits_q(amd):
     """ntt_goldilock.rs:107 (`res > q`): an exact sum of q is stored as q; the kernel reproduces it."""
     for n in (16, 256, 4096, 1 << 16):

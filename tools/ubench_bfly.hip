@@ -5,13 +5,13 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
-#include "../ntt_amd/csrc/arith.hpp"
+#include "../ntt_amd/csrc/kernels.hpp"
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 using namespace nttx;
 
 template <class A, bool FWD>
-__global__ __launch_bounds__(256) void k(uint64_t* out, const typename A::TwElem* tw, typename A::Ctx c, int iters)
+__global__ __launch_bounds__(256, 4) void k(uint64_t* out, const typename A::TwElem* tw, typename A::Ctx c, int iters)
 {
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t x[16];
@@ -21,19 +21,7 @@ __global__ __launch_bounds__(256) void k(uint64_t* out, const typename A::TwElem
 #pragma unroll
     for (int i = 1; i < 16; i++) w[i] = A::load(tw, (tid & 3) * 16 + i, c);
     for (int it = 0; it < iters; it++) {
-#pragma unroll
-        for (int u = 1; u <= 4; u++) {
-            const int half = 16 >> u;
-#pragma unroll
-            for (int b = 0; b < (1 << (u - 1)); b++) {
-#pragma unroll
-                for (int i = 0; i < half; i++) {
-                    const int lo = b * 2 * half + i, hi = lo + half;
-                    if (FWD) A::ct(x[lo], x[hi], w[(1 << (u - 1)) + b], c);
-                    else A::gs(x[lo], x[hi], w[(1 << (u - 1)) + b], c);
-                }
-            }
-        }
+        radix<A, 4, FWD>(x, RegTw<A, 4>{w}, c, false);
     }
 #pragma unroll
     for (int i = 0; i < 16; i++) out[tid * 16 + i] = x[i];

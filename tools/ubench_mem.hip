@@ -71,6 +71,21 @@ __global__ __launch_bounds__(256) void stream16(uint64_t* d, size_t n16)
     }
 }
 
+// one launch, every block sweeps its own set of 32 KiB tiles `reps` times (in place): the
+// region is re-read from wherever it stays resident (L2 if small per XCD, else Infinity Cache)
+__global__ __launch_bounds__(256) void resident16(uint64_t* d, int tiles_per_block, int reps)
+{
+    for (int r = 0; r < reps; r++)
+        for (int t = 0; t < tiles_per_block; t++) {
+            ulonglong2* p = reinterpret_cast<ulonglong2*>(d) + ((size_t)t * gridDim.x + blockIdx.x) * 2048 + threadIdx.x;
+            ulonglong2 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = p[i * 256];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { v[i].x += 1; p[i * 256] = v[i]; }
+        }
+}
+
 template <class F> void timeit(const char* name, F launch, double bytes)
 {
     hipEvent_t e0, e1;
@@ -105,6 +120,13 @@ int main()
         char name[64];
         snprintf(name, sizeof name, "inplace16 region %zu MiB x%d", mib, reps);
         timeit(name, [&] { for (int r = 0; r < reps; r++) inplace16<<<elems / 4096, 256>>>(d); }, bytes);
+    }
+    for (size_t mib : {16, 32, 64, 128, 192, 224, 512, 2048}) {
+        const int grid = 1024, tiles = (int)((mib << 20) / 32768 / grid);
+        const int reps = (int)(8192 / mib);
+        char name[64];
+        snprintf(name, sizeof name, "resident16 %zu MiB x%d one launch", mib, reps);
+        timeit(name, [&] { resident16<<<grid, 256>>>(d, tiles, reps); }, 2.0 * (double)(mib << 20) * reps);
     }
     return 0;
 }

@@ -60,6 +60,47 @@ __global__ __launch_bounds__(256) void k(uint64_t* out, uint32_t seed)
                 acc[i] = a + x + (uint32_t)acc[(i + 1) % ILP];
             } else if (OP == 13) {  // 64-bit sub
                 acc[i] = acc[i] - acc[(i + 1) % ILP];
+            } else if (OP == 20) {  // v_pk_mov_b32: (hi half, 0)
+                uint64_t d;
+                asm volatile("v_pk_mov_b32 %0, %1, 0 op_sel:[1,0]" : "=v"(d) : "v"(acc[i]));
+                acc[i] = d;
+            } else if (OP == 21) {  // v_lshrrev_b64
+                uint64_t d;
+                asm volatile("v_lshrrev_b64 %0, 1, %1" : "=v"(d) : "v"(acc[i]));
+                acc[i] = d;
+            } else if (OP == 22) {  // v_mov_b32
+                uint32_t d;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"((uint32_t)acc[i]));
+                acc[i] = d;
+            } else if (OP == 23) {  // v_max3_u32
+                uint32_t d;
+                asm volatile("v_max3_u32 %0, %1, %2, %3" : "=v"(d) : "v"((uint32_t)acc[i]), "v"(x), "v"(y));
+                acc[i] = d;
+            } else if (OP == 24) {  // v_lshl_add_u64
+                uint64_t d;
+                asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(acc[i]), "v"(acc[(i + 1) % ILP]));
+                acc[i] = d;
+            } else if (OP == 25) {  // v_cmp_eq_u32 to an SGPR pair + v_cndmask from it
+                uint32_t d;
+                uint64_t m;
+                asm volatile("v_cmp_eq_u32 %1, %2, %3\n\ts_nop 1\n\tv_cndmask_b32 %0, %2, %3, %1"
+                             : "=&v"(d), "=&s"(m) : "v"((uint32_t)acc[i]), "v"(x));
+                acc[i] = d;
+            } else if (OP == 26) {  // v_cmp_lt_u64 + cndmask
+                uint32_t d;
+                uint64_t m;
+                asm volatile("v_cmp_lt_u64 %1, %2, %3\n\ts_nop 1\n\tv_cndmask_b32 %0, 0, -1, %1"
+                             : "=&v"(d), "=&s"(m) : "v"(acc[i]), "v"(acc[(i + 1) % ILP]));
+                acc[i] = acc[i] ^ d;
+            } else if (OP == 27) {  // v_mov_b64
+                uint64_t d;
+                asm volatile("v_mov_b64 %0, %1" : "=v"(d) : "v"(acc[i]));
+                acc[i] = d;
+            } else if (OP == 28) {  // add_co + addc with s_nop between
+                uint32_t l, h;
+                asm volatile("v_add_co_u32 %0, vcc, %2, %4\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %3, %5, vcc"
+                             : "=&v"(l), "=&v"(h) : "v"((uint32_t)acc[i]), "v"((uint32_t)(acc[i] >> 32)), "v"(x), "v"(y) : "vcc");
+                acc[i] = ((uint64_t)h << 32) | l;
             } else if (OP == 9) {  // v_mad_u32_u24
                 uint32_t a = (uint32_t)acc[i];
                 acc[i] = __umul24(a, x) + a;
@@ -119,5 +160,14 @@ int main()
     run<11>("cmp64+select+add", 1);
     run<12>("add3 u32", 1);
     run<13>("sub64 reg-reg", 1);
+    run<22>("v_mov_b32", 1);
+    run<20>("v_pk_mov_b32", 1);
+    run<27>("v_mov_b64", 1);
+    run<21>("v_lshrrev_b64", 1);
+    run<23>("v_max3_u32", 1);
+    run<24>("v_lshl_add_u64", 1);
+    run<25>("cmp_eq_u32 + cndmask", 2);
+    run<26>("cmp_lt_u64 + cndmask + xor", 4);
+    run<28>("add_co/addc asm", 2);
     return 0;
 }
