@@ -114,6 +114,44 @@ int nttx_pass_describe(const nttx_plan *plan, int dir, int pass_index, char *buf
 int nttx_run_pass_device(const nttx_plan *plan, int device, void *dptr, size_t batch, int dir,
                          int pass_index, void *hip_stream);
 
+/*
+ * ONE transform of n elements split over n_shards = 2^k shards (a single vector too large or
+ * too slow for one GPU; the reference runs any length in one loop nest, ntt.rs:122-176 and
+ * :178-236, ntt_goldilock.rs:81-180 -- these calls compute the same result).  The split
+ * follows the reference's index structure: the first f butterfly stages (f = stage count of the
+ * first pass, nttx_pass_describe(plan, 0, 0)) only couple elements whose indices agree modulo
+ * n/2^f, and after them the vector is 2^f independent contiguous blocks.
+ *
+ *   column layout of shard d: a [rows = 2^f][cols = n/(2^f * n_shards)] array holding, of every
+ *     row of n/2^f consecutive elements of the vector, the columns [d*cols, (d+1)*cols).
+ *   block layout of shard c: elements [c*n/n_shards, (c+1)*n/n_shards) of the vector.
+ *   exchange: shard d's rows [c*rows_per_peer, (c+1)*rows_per_peer) (one contiguous piece) go to
+ *     shard c, which stores row rho of that piece at offset (rho*n_shards + d)*cols.
+ *
+ * Forward (natural order in column layout -> bit-reversed order in block layout):
+ *   phase 0 on every shard, exchange, phase 1.   Backward is the mirror image: phase 1 on the
+ *   block layout, the inverse exchange, phase 0 on the column layout (which applies n^-1).
+ *
+ * nttx_forward_distributed / nttx_backward_distributed do all of it for a vector in HOST memory
+ * from one process: shard i runs on plan device i % n_devices (n_shards = 0 means one shard per
+ * plan device), pieces move with device-to-device copies.  With a single device all shards share
+ * it, so the same code path can be tested on one GPU.
+ *
+ * nttx_shard_geometry and nttx_shard_phase_device are the building blocks for callers that run
+ * one process per GPU and do the exchange themselves (an all-to-all over RCCL):
+ * nttx_shard_phase_device enqueues the passes of one phase on one shard's device-resident buffer
+ * of local_elems elements.  dir = 0 forward, 1 backward.
+ *
+ * Limits: n_shards a power of two <= 2^f (f = 8 when log2 n is a multiple of 8, else log2 n mod
+ * 8), n >= 2^10 and n/n_shards >= 4096.  For the N = 2^28 vector over 8 GPUs f = 4.
+ */
+int nttx_forward_distributed(const nttx_plan *plan, uint64_t *host_data, int n_shards);
+int nttx_backward_distributed(const nttx_plan *plan, uint64_t *host_data, int n_shards);
+int nttx_shard_geometry(const nttx_plan *plan, int n_shards, uint64_t *local_elems, uint64_t *rows,
+                        uint64_t *cols, uint64_t *rows_per_peer);
+int nttx_shard_phase_device(const nttx_plan *plan, int device, void *dptr, int dir, int phase, int shard,
+                            int n_shards, void *hip_stream);
+
 int nttx_device_count(void);
 const char *nttx_last_error(void); /* thread-local, never NULL */
 const char *nttx_version(void);

@@ -25,6 +25,10 @@ SYMBOLS = {
     "nttx_pass_count": (C.c_int, [_vp]),
     "nttx_pass_describe": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, _sz]),
     "nttx_run_pass_device": (C.c_int, [_vp, C.c_int, _vp, _sz, C.c_int, C.c_int, _vp]),
+    "nttx_forward_distributed": (C.c_int, [_vp, _vp, C.c_int]),
+    "nttx_backward_distributed": (C.c_int, [_vp, _vp, C.c_int]),
+    "nttx_shard_geometry": (C.c_int, [_vp, C.c_int, _pu64, _pu64, _pu64, _pu64]),
+    "nttx_shard_phase_device": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "nttx_device_count": (C.c_int, []),
     "nttx_last_error": (C.c_char_p, []),
     "nttx_version": (C.c_char_p, []),

@@ -40,7 +40,9 @@ struct PassParams {
     uint64_t* data;
     const void* tw;           // device twiddle table of this direction, n entries of Arith::TwElem
     const void* tw_perm;      // same entries with the last four stages regrouped (see permuted_index)
-    uint64_t nblocks_total;   // batch << s0
+    uint64_t nblocks_total;   // blocks in the buffer: batch << s0, or one shard's share of a split transform
+    uint64_t block_base;      // index, inside its transform, of the buffer's first block (0 unless the
+                              // buffer is one shard of a transform split over several devices)
     uint32_t logB;            // log2 of the block size n >> s0
     uint32_t s0;              // stages that precede this pass in forward order
     uint32_t flags;
@@ -206,7 +208,7 @@ __device__ __forceinline__ uint32_t lds_addr(uint32_t sigma, uint32_t r)
 template <int K>
 struct TileGeom {
     uint32_t logB, logT, logCw, lognblk, logtpb, s0;
-    uint64_t tile, nblocks_total;
+    uint64_t tile, nblocks_total, block_base;
 
     __device__ __forceinline__ TileGeom(const PassParams& p, uint64_t tile_)
     {
@@ -219,6 +221,7 @@ struct TileGeom {
         logtpb = logT - logCw;
         tile = tile_;
         nblocks_total = p.nblocks_total;
+        block_base = p.block_base;
     }
     __device__ __forceinline__ uint64_t block_of(uint32_t sigma) const
     {
@@ -237,7 +240,7 @@ struct TileGeom {
     // twiddle base of the block: 2^s0 + (block index inside its transform)
     __device__ __forceinline__ uint64_t twiddle_base(uint32_t sigma) const
     {
-        return (1ull << s0) + (block_of(sigma) & ((1ull << s0) - 1));
+        return (1ull << s0) + ((block_base + block_of(sigma)) & ((1ull << s0) - 1));
     }
 };
 

@@ -131,51 +131,263 @@ int device_slot(const nttx_plan* plan, int device)
     return -1;
 }
 
+// Launches pass `d` with parameters `p` (data, geometry and flags already set) over `tiles` tiles.
+int launch_pass(const nttx_plan* plan, int slot, const PassDesc& d, PassParams p, uint64_t tiles, bool fwd,
+                hipStream_t stream)
+{
+    if (tiles == 0 || tiles > 0x7fffffffull)
+        return fail(NTTX_EINVAL, "element count is out of range for one launch");
+    p.tw = fwd ? plan->d_fwd[slot] : plan->d_inv[slot];
+    p.tw_perm = fwd ? plan->d_fwd_perm[slot] : plan->d_inv_perm[slot];
+    static const bool no_math = std::getenv("NTTX_DEBUG_NO_MATH") != nullptr;
+    if (no_math)
+        p.flags |= PASS_DEBUG_NO_MATH;
+    static const bool no_tw = std::getenv("NTTX_DEBUG_NO_TW") != nullptr;
+    if (no_tw)
+        p.flags |= PASS_DEBUG_NO_TW;
+    hipError_t e;
+    switch (plan->policy) {
+    case nttx_plan::GOLDILOCKS: e = launch_dir<Goldilocks>(fwd, d, p, plan->gctx, (unsigned)tiles, stream); break;
+    case nttx_plan::MONT_WIDE: e = launch_dir<Mont<true>>(fwd, d, p, plan->mctx, (unsigned)tiles, stream); break;
+    case nttx_plan::MONT: e = launch_dir<Mont<false>>(fwd, d, p, plan->mctx, (unsigned)tiles, stream); break;
+    default: e = launch_dir<Shoup61>(fwd, d, p, plan->sctx, (unsigned)tiles, stream); break;
+    }
+    if (e != hipSuccess)
+        return fail(NTTX_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return NTTX_OK;
+}
+
+// Flags of the pass at forward-order position `fi` of `np` when running direction `fwd`.
+uint32_t pass_flags(const PassDesc& d, size_t fi, size_t np, bool fwd)
+{
+    uint32_t flags = 0;
+    if (fwd ? fi == 0 : fi + 1 == np)
+        flags |= PASS_CONDITION_INPUT; // first pass to touch the caller's data
+    if (!fwd && d.s0 == 0)
+        flags |= PASS_SCALE;
+    if (fwd && fi + 1 == np)
+        flags |= PASS_FINISH;
+    return flags;
+}
+
 // Enqueues the passes of one transform direction for `batch` vectors at dptr.
 int enqueue_passes(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream,
                    int only_pass)
 {
     const uint64_t total = (uint64_t)batch << plan->logn;
     const uint64_t tiles = (total + TILE - 1) / TILE;
-    if (tiles > 0x7fffffffull)
-        return fail(NTTX_EINVAL, "batch * n is too large for one launch");
-
     const size_t np = plan->passes.size();
     for (size_t i = 0; i < np; i++) {
         if (only_pass >= 0 && (size_t)only_pass != i)
             continue;
-        const PassDesc& d = plan->passes[fwd ? i : np - 1 - i];
-        PassParams p;
+        const size_t fi = fwd ? i : np - 1 - i;
+        const PassDesc& d = plan->passes[fi];
+        PassParams p{};
         p.data = dptr;
-        p.tw = fwd ? plan->d_fwd[slot] : plan->d_inv[slot];
-        p.tw_perm = fwd ? plan->d_fwd_perm[slot] : plan->d_inv_perm[slot];
         p.nblocks_total = (uint64_t)batch << d.s0;
+        p.block_base = 0;
         p.logB = plan->logn - d.s0;
         p.s0 = d.s0;
-        p.flags = 0;
-        if (i == 0)
-            p.flags |= PASS_CONDITION_INPUT;
-        if (!fwd && d.s0 == 0)
-            p.flags |= PASS_SCALE;
-        if (fwd && i + 1 == np)
-            p.flags |= PASS_FINISH;
-        static const bool no_math = std::getenv("NTTX_DEBUG_NO_MATH") != nullptr;
-        if (no_math)
-            p.flags |= PASS_DEBUG_NO_MATH;
-        static const bool no_tw = std::getenv("NTTX_DEBUG_NO_TW") != nullptr;
-        if (no_tw)
-            p.flags |= PASS_DEBUG_NO_TW;
-        hipError_t e;
-        switch (plan->policy) {
-        case nttx_plan::GOLDILOCKS: e = launch_dir<Goldilocks>(fwd, d, p, plan->gctx, (unsigned)tiles, stream); break;
-        case nttx_plan::MONT_WIDE: e = launch_dir<Mont<true>>(fwd, d, p, plan->mctx, (unsigned)tiles, stream); break;
-        case nttx_plan::MONT: e = launch_dir<Mont<false>>(fwd, d, p, plan->mctx, (unsigned)tiles, stream); break;
-        default: e = launch_dir<Shoup61>(fwd, d, p, plan->sctx, (unsigned)tiles, stream); break;
-        }
-        if (e != hipSuccess)
-            return fail(NTTX_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+        p.flags = pass_flags(d, fi, np, fwd);
+        int rc = launch_pass(plan, slot, d, p, tiles, fwd, stream);
+        if (rc != NTTX_OK)
+            return rc;
     }
     return NTTX_OK;
+}
+
+// ---- one transform split over several shards ---------------------------------------------------
+//
+// The first forward pass (f stages, strides n/2 .. n/2^f) only couples elements whose indices
+// agree modulo n/2^f; after it the transform consists of 2^f independent contiguous blocks of
+// n/2^f elements (the reference's index structure, ntt.rs:129-171: stage u works inside blocks
+// of n/2^(u-1) and its twiddle index is 2^(u-1) + block).  With g = 2^k <= 2^f shards:
+//   column layout: shard d holds, of every one of the 2^f rows of n/2^f elements, the columns
+//                  [d*W, (d+1)*W), W = n/(2^f g), as a [2^f][W] array.  The first pass on it is
+//                  the first pass of a transform of length n/g with the same twiddles.
+//   block layout:  shard c holds elements [c*n/g, (c+1)*n/g): 2^f/g whole blocks.  All later
+//                  passes run on it with the twiddle block index offset by the shard.
+// Between the two every shard sends every other shard one [R][W] piece, R = 2^f/g rows.
+// Forward: column layout -> first pass -> exchange -> block layout -> remaining passes.
+// Backward mirrors it (ntt.rs:185-229): block layout -> all but the last pass -> exchange ->
+// column layout -> the pass with the first f stages (and the n^-1 factor).
+struct ShardGeom {
+    uint32_t k = 0, f = 0;   // log2(shards), stages before the exchange
+    uint64_t local = 0;      // elements per shard
+    uint64_t rows = 0;       // 2^f
+    uint64_t W = 0;          // columns per shard in the column layout
+    uint64_t R = 0;          // rows per destination shard
+};
+
+int shard_geometry(const nttx_plan* plan, int n_shards, ShardGeom& g)
+{
+    if (!plan)
+        return fail(NTTX_EINVAL, "plan is NULL");
+    if (n_shards < 1 || n_shards > 64 || (n_shards & (n_shards - 1)) != 0)
+        return fail(NTTX_EINVAL, "number of shards must be a power of two in [1, 64]");
+    if (plan->passes.size() < 2)
+        return fail(NTTX_EINVAL, "n is too small to split (needs n >= 2^10)");
+    g.k = ntt::host::ilog2((uint64_t)n_shards);
+    g.f = (uint32_t)(plan->passes[0].k1 + plan->passes[0].k2);
+    if (g.f < g.k)
+        return fail(NTTX_EINVAL, "too many shards for this n: the first pass has fewer stages than log2(shards)");
+    if (plan->logn < g.f + g.k + 4 || plan->logn < g.k + TILE_LOG)
+        return fail(NTTX_EINVAL, "n is too small for this number of shards");
+    g.local = plan->n >> g.k;
+    g.rows = 1ull << g.f;
+    g.W = plan->n >> (g.f + g.k);
+    g.R = g.rows >> g.k;
+    return NTTX_OK;
+}
+
+// Enqueues on one shard's buffer the passes of `phase` (0: the first forward pass, column layout;
+// 1: all other passes, block layout) for direction `fwd`.
+int enqueue_shard_phase(const nttx_plan* plan, int slot, uint64_t* dptr, bool fwd, int phase, int shard,
+                        const ShardGeom& g, hipStream_t stream)
+{
+    const size_t np = plan->passes.size();
+    const uint64_t tiles = g.local / TILE;
+    for (size_t i = 0; i < np; i++) {
+        const size_t fi = fwd ? i : np - 1 - i;
+        const PassDesc& d = plan->passes[fi];
+        if ((phase == 0) != (fi == 0))
+            continue;
+        PassParams p{};
+        p.data = dptr;
+        p.s0 = d.s0;
+        if (fi == 0) {
+            p.nblocks_total = 1;
+            p.block_base = 0;
+            p.logB = plan->logn - g.k;
+        } else {
+            p.nblocks_total = (1ull << d.s0) >> g.k;
+            p.block_base = (uint64_t)shard * p.nblocks_total;
+            p.logB = plan->logn - d.s0;
+        }
+        p.flags = pass_flags(d, fi, np, fwd);
+        int rc = launch_pass(plan, slot, d, p, tiles, fwd, stream);
+        if (rc != NTTX_OK)
+            return rc;
+    }
+    return NTTX_OK;
+}
+
+// Whole split transform driven from one process: shard i lives on plan device i % n_devices
+// (with one device all shards share it, which exercises the same code on a single GPU).
+int run_distributed(const nttx_plan* plan, uint64_t* host, bool fwd, int n_shards)
+{
+    if (!plan)
+        return fail(NTTX_EINVAL, "plan is NULL");
+    if (!host)
+        return fail(NTTX_EINVAL, "data is NULL");
+    const int ndev = (int)plan->devices.size();
+    const int gs = n_shards == 0 ? ndev : n_shards; // negative values fail the geometry check
+    ShardGeom g;
+    int rc = shard_geometry(plan, gs, g);
+    if (rc != NTTX_OK)
+        return rc;
+    struct Shard {
+        int dev = 0, slot = 0;
+        hipStream_t s = nullptr;
+        uint64_t *col = nullptr, *blk = nullptr; // column-layout and block-layout buffers
+    };
+    std::vector<Shard> sh((size_t)gs);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    const size_t bytes = g.local * sizeof(uint64_t);
+    const size_t wbytes = g.W * sizeof(uint64_t);
+    const size_t row_pitch = (plan->n >> g.f) * sizeof(uint64_t); // host pitch between rows
+
+    auto sync_all = [&]() -> int {
+        for (auto& x : sh) {
+            HIP_TRY(hipSetDevice(x.dev));
+            HIP_TRY(hipStreamSynchronize(x.s));
+        }
+        return NTTX_OK;
+    };
+    // piece (rho, d) of shard c's block layout <-> rows c*R + rho of shard d's column layout
+    auto exchange = [&](bool to_blocks) -> int {
+        for (int c = 0; c < gs; c++)
+            for (int d = 0; d < gs; d++) {
+                Shard& owner = to_blocks ? sh[(size_t)c] : sh[(size_t)d]; // copies run on the receiver's stream
+                HIP_TRY(hipSetDevice(owner.dev));
+                for (uint64_t rho = 0; rho < g.R; rho++) {
+                    uint64_t* in_blk = sh[(size_t)c].blk + (rho * (uint64_t)gs + (uint64_t)d) * g.W;
+                    uint64_t* in_col = sh[(size_t)d].col + ((uint64_t)c * g.R + rho) * g.W;
+                    if (to_blocks)
+                        HIP_TRY(hipMemcpyPeerAsync(in_blk, sh[(size_t)c].dev, in_col, sh[(size_t)d].dev, wbytes, owner.s));
+                    else
+                        HIP_TRY(hipMemcpyPeerAsync(in_col, sh[(size_t)d].dev, in_blk, sh[(size_t)c].dev, wbytes, owner.s));
+                }
+            }
+        return NTTX_OK;
+    };
+    auto body = [&]() -> int {
+        for (int i = 0; i < gs; i++) {
+            Shard& x = sh[(size_t)i];
+            x.slot = i % ndev;
+            x.dev = plan->devices[(size_t)x.slot];
+            HIP_TRY(hipSetDevice(x.dev));
+            HIP_TRY(hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking));
+            HIP_TRY(hipMalloc(&x.col, bytes));
+            HIP_TRY(hipMalloc(&x.blk, bytes));
+        }
+        int r;
+        if (fwd) {
+            for (int d = 0; d < gs; d++) {
+                Shard& x = sh[(size_t)d];
+                HIP_TRY(hipSetDevice(x.dev));
+                HIP_TRY(hipMemcpy2DAsync(x.col, wbytes, host + (uint64_t)d * g.W, row_pitch, wbytes, g.rows,
+                                         hipMemcpyHostToDevice, x.s));
+                if ((r = enqueue_shard_phase(plan, x.slot, x.col, true, 0, d, g, x.s)) != NTTX_OK)
+                    return r;
+            }
+            if ((r = sync_all()) != NTTX_OK || (r = exchange(true)) != NTTX_OK || (r = sync_all()) != NTTX_OK)
+                return r;
+            for (int c = 0; c < gs; c++) {
+                Shard& x = sh[(size_t)c];
+                HIP_TRY(hipSetDevice(x.dev));
+                if ((r = enqueue_shard_phase(plan, x.slot, x.blk, true, 1, c, g, x.s)) != NTTX_OK)
+                    return r;
+                HIP_TRY(hipMemcpyAsync(host + (uint64_t)c * g.local, x.blk, bytes, hipMemcpyDeviceToHost, x.s));
+            }
+        } else {
+            for (int c = 0; c < gs; c++) {
+                Shard& x = sh[(size_t)c];
+                HIP_TRY(hipSetDevice(x.dev));
+                HIP_TRY(hipMemcpyAsync(x.blk, host + (uint64_t)c * g.local, bytes, hipMemcpyHostToDevice, x.s));
+                if ((r = enqueue_shard_phase(plan, x.slot, x.blk, false, 1, c, g, x.s)) != NTTX_OK)
+                    return r;
+            }
+            if ((r = sync_all()) != NTTX_OK || (r = exchange(false)) != NTTX_OK || (r = sync_all()) != NTTX_OK)
+                return r;
+            for (int d = 0; d < gs; d++) {
+                Shard& x = sh[(size_t)d];
+                HIP_TRY(hipSetDevice(x.dev));
+                if ((r = enqueue_shard_phase(plan, x.slot, x.col, false, 0, d, g, x.s)) != NTTX_OK)
+                    return r;
+                HIP_TRY(hipMemcpy2DAsync(host + (uint64_t)d * g.W, row_pitch, x.col, wbytes, wbytes, g.rows,
+                                         hipMemcpyDeviceToHost, x.s));
+            }
+        }
+        return sync_all();
+    };
+    rc = body();
+    for (auto& x : sh) {
+        if (!x.s && !x.col && !x.blk)
+            continue;
+        (void)hipSetDevice(x.dev);
+        if (x.s) {
+            (void)hipStreamSynchronize(x.s);
+            (void)hipStreamDestroy(x.s);
+        }
+        if (x.col)
+            (void)hipFree(x.col);
+        if (x.blk)
+            (void)hipFree(x.blk);
+    }
+    (void)hipSetDevice(prev);
+    return rc;
 }
 
 // Optional chunking of a batch: with NTTX_CHUNK_MIB=<m> all passes run over m MiB of the batch
@@ -549,6 +761,54 @@ int nttx_run_pass_device(const nttx_plan* plan, int device, void* dptr, size_t b
     if (!plan || pass_index < 0 || pass_index >= (int)plan->passes.size() || (dir != 0 && dir != 1))
         return fail(NTTX_EINVAL, "pass index or direction out of range");
     return run_device(plan, device, dptr, batch, hip_stream, dir == 0, pass_index);
+}
+
+int nttx_forward_distributed(const nttx_plan* plan, uint64_t* host_data, int n_shards)
+{
+    return run_distributed(plan, host_data, true, n_shards);
+}
+int nttx_backward_distributed(const nttx_plan* plan, uint64_t* host_data, int n_shards)
+{
+    return run_distributed(plan, host_data, false, n_shards);
+}
+
+int nttx_shard_geometry(const nttx_plan* plan, int n_shards, uint64_t* local_elems, uint64_t* rows, uint64_t* cols,
+                        uint64_t* rows_per_peer)
+{
+    ShardGeom g;
+    int rc = shard_geometry(plan, n_shards, g);
+    if (rc != NTTX_OK)
+        return rc;
+    if (local_elems) *local_elems = g.local;
+    if (rows) *rows = g.rows;
+    if (cols) *cols = g.W;
+    if (rows_per_peer) *rows_per_peer = g.R;
+    return NTTX_OK;
+}
+
+int nttx_shard_phase_device(const nttx_plan* plan, int device, void* dptr, int dir, int phase, int shard, int n_shards,
+                            void* hip_stream)
+{
+    ShardGeom g;
+    int rc = shard_geometry(plan, n_shards, g);
+    if (rc != NTTX_OK)
+        return rc;
+    if ((dir != 0 && dir != 1) || (phase != 0 && phase != 1) || shard < 0 || shard >= n_shards)
+        return fail(NTTX_EINVAL, "direction, phase or shard out of range");
+    const int slot = device_slot(plan, device);
+    if (slot < 0)
+        return fail(NTTX_ENODEV, "device is not one of the plan's devices");
+    if (!dptr || (reinterpret_cast<uintptr_t>(dptr) & 15))
+        return fail(NTTX_EINVAL, "device pointer must be non-NULL and 16-byte aligned");
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != device)
+        HIP_TRY(hipSetDevice(device));
+    rc = enqueue_shard_phase(plan, slot, static_cast<uint64_t*>(dptr), dir == 0, phase, shard, g,
+                             static_cast<hipStream_t>(hip_stream));
+    if (cur != device && cur >= 0)
+        (void)hipSetDevice(cur);
+    return rc;
 }
 
 int nttx_device_count(void)

@@ -129,6 +129,29 @@ class _PlanTable(DFT):
     def backward_inplace_batch(self, x, batch):
         self._run_batch(x, batch, False)
 
+    # ONE transform split over several shards (a vector too large for one GPU); same result as
+    # forward_inplace / backward_inplace on the whole slice.  n_shards = 0: one per plan device.
+    def forward_inplace_distributed(self, x, n_shards=0):
+        self._run_distributed(x, n_shards, True)
+
+    def backward_inplace_distributed(self, x, n_shards=0):
+        self._run_distributed(x, n_shards, False)
+
+    def _run_distributed(self, x, n_shards, forward):
+        if not isinstance(x, np.ndarray) or x.dtype != self._np_dtype or not x.flags.c_contiguous \
+                or not x.flags.writeable:
+            raise TypeError("expected a writable C-contiguous %s array" % np.dtype(self._np_dtype).name)
+        if x.size != self._n:
+            raise Panic("slice length %d != table size %d" % (x.size, self._n))
+        fn = lib.nttx_forward_distributed if forward else lib.nttx_backward_distributed
+        _check(fn(self._plan, x.ctypes.data, n_shards))
+
+    def shard_geometry(self, n_shards):
+        """(local_elems, rows, cols, rows_per_peer) of the split described in include/nttx.h."""
+        v = [C.c_uint64() for _ in range(4)]
+        _check(lib.nttx_shard_geometry(self._plan, n_shards, *[C.byref(t) for t in v]))
+        return tuple(t.value for t in v)
+
     def _run_batch(self, x, batch, forward):
         if x.dtype != self._np_dtype or not x.flags.c_contiguous or x.size != batch * self._n:
             raise Panic("expected batch * n contiguous elements")

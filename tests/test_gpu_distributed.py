@@ -1,0 +1,121 @@
+"""GPU parity of ONE transform split over several shards (include/nttx.h, "distributed").
+
+The reference computes a transform of any length in one loop nest (ntt.rs:122-176, :178-236;
+ntt_goldilock.rs:81-180); the split must give the same bits.  On the one-GPU test box all shards
+share device 0: nttx_forward_distributed places shard i on plan device i % n_devices, so the
+kernels, the shard twiddle offsets and the exchange run exactly as they do with one GPU per
+shard; only the copies stay on one device.  The one-process-per-GPU flavour (ShardedTransform
+over torch.distributed) is run with 2 and 4 ranks sharing the GPU and gloo carrying the pieces.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import _oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+Q61 = 0x1FFFFFFFFFE00001
+PSI61_2_21 = 0x0B4F9CB5C38B40B1
+QGL = 0xFFFFFFFF00000001
+
+
+def tables(amd, kind, n):
+    if kind == "mont":
+        psi = pow(PSI61_2_21, (1 << 20) // n, Q61)
+        return (amd.Table.from_prime_and_root(Q61, psi, n), orc.Table.from_prime_and_root(Q61, psi, n), Q61)
+    psi = pow(7, (QGL - 1) // (2 * n), QGL)
+    return amd.TableGoldilock.from_root(psi, n), orc.TableGoldilock.from_root(psi, n), QGL
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import ntt_amd
+    return ntt_amd
+
+
+@pytest.mark.parametrize("kind", ["mont", "goldilocks"])
+@pytest.mark.parametrize("logn", [16, 18, 20])
+def test_virtual_shards_match_oracle(amd, kind, logn):
+    n = 1 << logn
+    gpu, ref, q = tables(amd, kind, n)
+    x = orc.splitmix_residues(q, n, 500 + logn)
+    want = x.copy()
+    ref.forward_inplace(want)
+    f = logn % 8 or 8
+    for shards in (1, 2, 4, 8, 16):
+        if shards > (1 << f) or logn < f + (shards.bit_length() - 1) + 4:
+            continue
+        assert gpu.shard_geometry(shards) == amd.distributed.split_geometry(n, shards)
+        a = x.copy()
+        gpu.forward_inplace_distributed(a, shards)
+        assert np.array_equal(a, want), "forward, %d shards" % shards
+        gpu.backward_inplace_distributed(a, shards)
+        assert np.array_equal(a, x), "backward, %d shards" % shards
+
+
+def test_goldilocks_out_of_range_input_split(amd):
+    """TableGoldilock takes any u64 (no input sweep); the split must follow the same rules."""
+    n = 1 << 16
+    gpu, ref, _ = tables(amd, "goldilocks", n)
+    rng = np.random.default_rng(3)
+    raw = rng.integers(0, 2**64, n, dtype=np.uint64)
+    raw[:4] = [2**64 - 1, QGL, QGL + 1, QGL - 1]
+    for fn in ("forward_inplace", "backward_inplace"):
+        a, w = raw.copy(), raw.copy()
+        getattr(gpu, fn + "_distributed")(a, 8)
+        getattr(ref, fn)(w)
+        assert np.array_equal(a, w), fn
+
+
+def test_split_limits(amd):
+    gpu, _, _ = tables(amd, "goldilocks", 1 << 20)            # first pass has 4 stages
+    a = np.zeros(1 << 20, dtype=np.uint64)
+    for bad in (3, 32, 128, -1):
+        with pytest.raises(amd.Panic):
+            gpu.forward_inplace_distributed(a, bad)
+    small, _, _ = tables(amd, "goldilocks", 1 << 8)           # single-pass transform: nothing to split
+    with pytest.raises(amd.Panic):
+        small.forward_inplace_distributed(np.zeros(1 << 8, dtype=np.uint64), 2)
+    with pytest.raises(amd.Panic):
+        gpu.forward_inplace_distributed(np.zeros(1 << 16, dtype=np.uint64), 2)   # wrong length
+
+
+def test_two_to_the_24_eight_shards(amd):
+    """First pass with 8 stages (32 rows per peer), three passes in all."""
+    n = 1 << 24
+    gpu, ref, q = tables(amd, "goldilocks", n)
+    x = orc.splitmix_residues(q, n, 524)
+    want = x.copy()
+    ref.forward_inplace(want)
+    a = x.copy()
+    gpu.forward_inplace_distributed(a, 8)
+    assert np.array_equal(a, want)
+    gpu.backward_inplace_distributed(a, 8)
+    assert np.array_equal(a, x)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("world,kind,logn", [(2, "mont", 16), (4, "goldilocks", 20)])
+def test_one_process_per_shard(tmp_path, world, kind, logn):
+    """ShardedTransform over torch.distributed; the ranks share GPU 0, so gloo carries the pieces."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(HERE, "dist_gpu_worker.py"), kind, str(logn), str(tmp_path)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    for r in range(world):
+        assert (tmp_path / ("ok%d" % r)).exists(), res.stdout[-2000:] + res.stderr[-2000:]
