@@ -32,6 +32,7 @@ WORKLOADS = {
     "mont16": ("mont", 16, 4096, "batch %d x N=2^16 Montgomery 61-bit fwd+inv per GPU (BASELINE configs[1])"),
     "goldilocks20": ("goldilocks", 20, 256, "batch %d x N=2^20 Goldilocks fwd+inv per GPU (BASELINE configs[2])"),
     "goldilocks16": ("goldilocks", 16, 4096, "batch %d x N=2^16 Goldilocks fwd+inv per GPU"),
+    "goldilocks28": ("goldilocks", 28, 1, "%d x N=2^28 Goldilocks fwd+inv on one GPU (BASELINE configs[4]'s vector, unsplit)"),
 }
 
 

@@ -119,3 +119,36 @@ def test_one_process_per_shard(tmp_path, world, kind, logn):
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     for r in range(world):
         assert (tmp_path / ("ok%d" % r)).exists(), res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def test_two_to_the_28_goldilocks(amd):
+    """BASELINE configs[4]'s vector: N = 2^28, Goldilocks, psi = 7^((q-1)/2^29), split over 8 shards
+    (first pass 4 stages, 2 rows per peer, 16 MiB pieces).  Checked against the oracle's transform
+    of the whole vector, against the unsplit GPU transform, and by the round trip."""
+    import time
+    n = 1 << 28
+    psi = pow(7, (QGL - 1) // (2 * n), QGL)
+    assert psi == 0xDFA8C93BA46D2666
+    t0 = time.time()
+    gpu = amd.TableGoldilock.from_root(psi, n)
+    assert gpu.n_inv == 0xFFFFFFEF00000011
+    assert gpu.shard_geometry(8) == (1 << 25, 16, 1 << 21, 2)
+    t1 = time.time()
+    x = orc.splitmix_residues(QGL, n, 528)
+    split = x.copy()
+    gpu.forward_inplace_distributed(split, 8)
+    whole = x.copy()
+    gpu.forward_inplace(whole)
+    assert np.array_equal(split, whole), "split and unsplit GPU transforms differ"
+    del whole
+    t2 = time.time()
+    ref = orc.TableGoldilock.from_root(psi, n)
+    want = x.copy()
+    ref.forward_inplace(want)
+    del ref
+    t3 = time.time()
+    assert np.array_equal(split, want), "GPU transform differs from the oracle"
+    del want
+    gpu.backward_inplace_distributed(split, 8)
+    assert np.array_equal(split, x), "round trip"
+    print("2^28: plan %.1fs, gpu %.1fs, oracle %.1fs, backward %.1fs" % (t1 - t0, t2 - t1, t3 - t2, time.time() - t3))
