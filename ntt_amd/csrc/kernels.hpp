@@ -33,7 +33,10 @@ enum : uint32_t {
     PASS_SCALE = 2u,           // pass holding stage 1 of the inverse: fold the n^-1 factor in
     PASS_FINISH = 4u,          // last pass of the forward transform: store canonical residues
     PASS_DEBUG_NO_MATH = 8u,   // profiling aid (NTTX_DEBUG_NO_MATH=1): skip the butterflies, keep all traffic
-    PASS_DEBUG_NO_TW = 16u     // profiling aid (NTTX_DEBUG_NO_TW=1, with NO_MATH): skip the twiddle loads too
+    PASS_DEBUG_NO_TW = 16u,    // profiling aid (NTTX_DEBUG_NO_TW=1, with NO_MATH): skip the twiddle loads too
+    PASS_DEBUG_NO_MATH_A = 32u, // profiling aids (NTTX_DEBUG_NO_MATH=A / B): skip one register round of the 8-stage pass
+    PASS_DEBUG_NO_MATH_B = 64u,
+    PASS_CROSS_BATCH = 128u    // CONTIG 8-stage pass: a tile is the same 256-element block of 16 consecutive transforms
 };
 
 struct PassParams {
@@ -209,6 +212,7 @@ template <int K>
 struct TileGeom {
     uint32_t logB, logT, logCw, lognblk, logtpb, s0;
     uint64_t tile, nblocks_total, block_base;
+    bool cross_batch;
 
     __device__ __forceinline__ TileGeom(const PassParams& p, uint64_t tile_)
     {
@@ -222,9 +226,16 @@ struct TileGeom {
         tile = tile_;
         nblocks_total = p.nblocks_total;
         block_base = p.block_base;
+        cross_batch = p.flags & PASS_CROSS_BATCH;
     }
+    // Block (of 2^logB elements, counted over the whole buffer) that sub-transform sigma belongs to.
+    // Ordinarily a tile takes consecutive blocks.  A cross-batch tile (CONTIG, K = 8: blocks are
+    // its 16 sub-transforms) takes block `tile mod 2^s0` of 16 consecutive transforms instead, so
+    // all its sub-transforms use the same twiddles.
     __device__ __forceinline__ uint64_t block_of(uint32_t sigma) const
     {
+        if (cross_batch)
+            return ((((tile >> s0) << 4) + sigma) << s0) + (tile & ((1ull << s0) - 1));
         return ((tile >> logtpb) << lognblk) + (sigma >> logCw);
     }
     __device__ __forceinline__ uint64_t column_of(uint32_t sigma) const
@@ -358,21 +369,49 @@ __device__ __forceinline__ void do_round(const PassParams& p, const TileGeom<K1 
     }
 }
 
-// Copies a CONTIG tile between HBM and LDS, 16 bytes per lane.
-template <class A, int K, bool TO_LDS>
+// Orders this wave's LDS writes before its later LDS reads from other lanes' addresses (LDS
+// executes a wave's instructions in order; this only stops the compiler from moving them).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Copies a CONTIG tile between HBM and LDS, 16 bytes per lane.  XB: the tile is 16 runs of 256
+// elements (cross-batch tile) instead of one run of 4096.
+// PER_WAVE: every wave moves its own quarter of the tile (elements [1024 w, 1024 w + 1024)).
+template <class A, int K, bool TO_LDS, bool XB = false, bool PER_WAVE = false>
 __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<K>& g, const typename A::Ctx& c,
                                             uint64_t* lds)
 {
     const uint64_t total = p.nblocks_total << p.logB;
     const uint64_t base = g.tile << TILE_LOG;
+    // element handled in step i
+    auto elem = [](int i) -> uint32_t {
+        if (PER_WAVE)
+            return (threadIdx.x >> 6) * (TILE / 4) + 2 * (i * 64 + (threadIdx.x & 63));
+        return 2 * (i * THREADS + threadIdx.x);
+    };
+    // element f of the tile: its address and whether it exists (f is even; pairs never straddle runs)
+    auto where = [&](uint32_t f, uint64_t*& ptr) -> bool {
+        if (XB) {
+            const uint32_t sigma = f >> K;
+            ptr = p.data + g.gidx(sigma, f & ((1u << K) - 1));
+            return g.valid(sigma);
+        }
+        ptr = p.data + base + f;
+        return base + f < total; // total is a multiple of 4 (n >= 4)
+    };
     if (TO_LDS) {
         uint64_t x[REGS];
 #pragma unroll
         for (int i = 0; i < REGS / 2; i++) {
-            const uint32_t f = 2 * (i * THREADS + threadIdx.x);
+            const uint32_t f = elem(i);
             ulonglong2 v = make_ulonglong2(0, 0);
-            if (base + f < total) // total is a multiple of 4 (n >= 4), f even
-                v = *reinterpret_cast<const ulonglong2*>(p.data + base + f);
+            uint64_t* src;
+            if (where(f, src))
+                v = *reinterpret_cast<const ulonglong2*>(src);
             x[2 * i] = v.x;
             x[2 * i + 1] = v.y;
         }
@@ -380,7 +419,7 @@ __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<
             condition_all<A, REGS>(x, c);
 #pragma unroll
         for (int i = 0; i < REGS / 2; i++) {
-            const uint32_t f = 2 * (i * THREADS + threadIdx.x);
+            const uint32_t f = elem(i);
             const uint32_t a0 = f + (f >> 4); // f is even, so f and f+1 share a padding group
             lds[a0] = x[2 * i];
             lds[a0 + 1] = x[2 * i + 1];
@@ -388,13 +427,14 @@ __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<
     } else {
 #pragma unroll
         for (int i = 0; i < REGS / 2; i++) {
-            const uint32_t f = 2 * (i * THREADS + threadIdx.x);
+            const uint32_t f = elem(i);
             const uint32_t a0 = f + (f >> 4);
-            if (base + f < total) {
+            uint64_t* dst;
+            if (where(f, dst)) {
                 ulonglong2 v;
                 v.x = lds[a0];
                 v.y = lds[a0 + 1];
-                *reinterpret_cast<ulonglong2*>(p.data + base + f) = v;
+                *reinterpret_cast<ulonglong2*>(dst) = v;
             }
         }
     }
@@ -423,19 +463,29 @@ __host__ __device__ inline uint64_t permuted_index(uint64_t idx, uint32_t logn)
 
 // The 8-stage pass (two radix-16 rounds, one group per thread).
 //
-// Twiddles: of the two rounds, one needs 16 sets of 15 twiddles per workgroup (one set per
-// 16 lanes) and the other either a single set (STRIDED, round A) or one set per thread (CONTIG,
-// round B, the last four stages of the transform).  The shared sets are fetched once per
-// workgroup -- one 16-byte load per thread -- into a 4 KiB LDS table and read at the point of
-// use; the per-thread sets come from the regrouped table with lane-contiguous loads, requested
-// before the workgroup barrier so their latency overlaps the LDS exchange.
+// Twiddles.  Three tile kinds:
+//   STRIDED           round A: one set of 15 for the whole tile; round B: 16 sets, one per rhigh.
+//   CONTIG cross-batch (XB: the same 256-element block of 16 transforms) -- the same as STRIDED.
+//   CONTIG plain      round A: 16 sets, one per sub-transform; round B: one set per thread (the
+//                     last four stages of one transform have n/16 distinct sets).
+// Shared sets are fetched once per workgroup -- one 16-byte load per thread -- into an LDS table
+// (set s at entry 17 s: the odd stride keeps the 16 sets a wave may read at once on different
+// banks) and read at the point of use; per-thread sets come from the regrouped table with
+// lane-contiguous loads, requested before the workgroup barrier so their latency overlaps the LDS
+// exchange.  The plain CONTIG tile spends 60 registers on them and reads as many twiddle bytes as
+// data bytes, which is why batches of 16 or more transforms take the cross-batch tile.
 //
 // Data: in a CONTIG tile the round with 128-byte runs (round A) talks to HBM directly; the
 // other side goes through LDS for 16-byte-per-lane coalescing.
-template <class A, bool FWD, bool CONTIG>
+constexpr int TW_SET_STRIDE = 17;
+constexpr int LDSTW_ELEMS = 16 * TW_SET_STRIDE + 16;
+
+template <class A, bool FWD, bool CONTIG, bool XB>
 __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8>& g, const typename A::Ctx& c,
                                        uint64_t* lds, typename A::TwElem* ldstw)
 {
+    static_assert(CONTIG || !XB, "cross-batch tiles are CONTIG tiles");
+    constexpr bool SHARED_B = !CONTIG || XB; // round B reads shared sets, round A the single set
     using RA = Round<A, CONTIG, 4, 4, true>;
     using RB = Round<A, CONTIG, 4, 4, false>;
     using TwElem = typename A::TwElem;
@@ -446,26 +496,32 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8>& g
     uint64_t x[16];
     const bool scale = p.flags & PASS_SCALE;
     const bool math = !(p.flags & PASS_DEBUG_NO_MATH);
+    const bool math_a = math && !(p.flags & PASS_DEBUG_NO_MATH_A), math_b = math && !(p.flags & PASS_DEBUG_NO_MATH_B);
     const bool twl = !(p.flags & PASS_DEBUG_NO_TW);
 
     // ---- stage the shared twiddle sets: thread t fetches entry j = t & 15 of set t >> 4 ----
     const uint32_t set = threadIdx.x >> 4, j = threadIdx.x & 15;
     const uint32_t u = 32 - __clz(j | 1);           // stage of entry j (j = 0 is unused)
     const uint32_t b = j ? j - (1u << (u - 1)) : 0;
-    // STRIDED: set = rhigh of round B, base (P << 4) + set; CONTIG: set = sigma of round A
-    const uint64_t Pset = CONTIG ? (g.valid(set) ? g.twiddle_base(set) : 1)
-                                 : ((g.twiddle_base(0) << 4) + set);
+    // SHARED_B: set = rhigh of round B, base (P << 4) + set; plain CONTIG: set = sigma of round A
+    const uint64_t Pset = SHARED_B ? ((g.twiddle_base(0) << 4) + set) : (g.valid(set) ? g.twiddle_base(set) : 1);
     // moved as raw dwords: a struct temporary held across the data loads ends up on the stack
     using Raw = __attribute__((ext_vector_type(sizeof(TwElem) / 4))) uint32_t;
     const Raw mine = *reinterpret_cast<const Raw*>(tw + ((Pset << (u - 1)) + b));
-    const Raw uni = *reinterpret_cast<const Raw*>(tw + ((g.twiddle_base(0) << (u - 1)) + b)); // threads 0..15, STRIDED
-    // the single set of STRIDED round A sits after the 16 sets
+    const Raw uni = *reinterpret_cast<const Raw*>(tw + ((g.twiddle_base(0) << (u - 1)) + b)); // threads 0..15, SHARED_B
+    // the single set of round A sits after the 16 sets
     TwElem* const shared_sets = ldstw;
-    TwElem* const uniform_set = ldstw + 256;
-    Raw* const shared_raw = reinterpret_cast<Raw*>(shared_sets);
-    Raw* const uniform_raw = reinterpret_cast<Raw*>(uniform_set);
+    TwElem* const uniform_set = ldstw + 16 * TW_SET_STRIDE;
+    auto stage_twiddles = [&]() {
+        reinterpret_cast<Raw*>(shared_sets)[set * TW_SET_STRIDE + j] = mine;
+        if (SHARED_B && threadIdx.x < 16)
+            reinterpret_cast<Raw*>(uniform_set)[threadIdx.x] = uni;
+    };
+    // the set each round reads
+    const TwElem* const set_a = SHARED_B ? uniform_set : shared_sets + ra.sigma * TW_SET_STRIDE;
+    const TwElem* const set_b = shared_sets + (CONTIG ? (threadIdx.x & 15) : (threadIdx.x >> 4)) * TW_SET_STRIDE;
 
-    // per-thread twiddles of CONTIG round B: entry (1 << (v-1)) + i <- regrouped table
+    // per-thread twiddles of plain CONTIG round B: entry (1 << (v-1)) + i <- regrouped table
     auto load_last = [&](typename A::Tw (&w)[16]) {
         const uint64_t beta16 = (rb.P >> 4) << 4;   // twiddle base of rhigh = 0 in this sub-transform
         const uint32_t rhigh = (uint32_t)(rb.P & 15);
@@ -481,32 +537,36 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8>& g
 
     if (FWD) {
         ra.load_global(x, p, g, c);
-        shared_raw[threadIdx.x] = mine;
-        if (!CONTIG && threadIdx.x < 16)
-            uniform_raw[threadIdx.x] = uni;
+        stage_twiddles();
         __syncthreads();
-        // round A: STRIDED reads the single set, CONTIG the set of its sub-transform
-        if (math)
-            radix<A, 4, true>(x, LdsTw<A>{CONTIG ? shared_sets + (ra.sigma << 4) : uniform_set, c}, c, false);
+        if (math_a)
+            radix<A, 4, true>(x, LdsTw<A>{set_a, c}, c, false);
         ra.store_lds(x, lds);
         if (CONTIG) {
             typename A::Tw w[16];
-            if (twl)
+            if (!SHARED_B && twl)
                 load_last(w);
             __syncthreads();
             rb.load_lds(x, lds);
-            if (math)
-                radix<A, 4, true>(x, RegTw<A, 4>{w}, c, false);
+            if (math_b) {
+                if constexpr (SHARED_B)
+                    radix<A, 4, true>(x, LdsTw<A>{set_b, c}, c, false);
+                else
+                    radix<A, 4, true>(x, RegTw<A, 4>{w}, c, false);
+            }
             if (p.flags & PASS_FINISH)
                 finish_all<A, 16>(x, c);
+            // Round B left each wave with four whole 256-element sub-transforms, so the way back
+            // to HBM (16 bytes per lane) only moves data between lanes of one wave: no workgroup
+            // barrier, the waves leave as they finish.
             rb.store_lds(x, lds); // the addresses this thread just read: no hazard with other threads
-            __syncthreads();
-            copy_contig<A, 8, false>(p, g, c, lds);
+            wave_sync();
+            copy_contig<A, 8, false, XB, true>(p, g, c, lds);
         } else {
             __syncthreads();
             rb.load_lds(x, lds);
-            if (math)
-                radix<A, 4, true>(x, LdsTw<A>{shared_sets + ((threadIdx.x >> 4) << 4), c}, c, false);
+            if (math_b)
+                radix<A, 4, true>(x, LdsTw<A>{set_b, c}, c, false);
             if (p.flags & PASS_FINISH)
                 finish_all<A, 16>(x, c);
             rb.store_global(x, p, g);
@@ -514,34 +574,36 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8>& g
     } else {
         if (CONTIG) {
             typename A::Tw w[16];
-            if (twl)
+            if (!SHARED_B && twl)
                 load_last(w);
-            copy_contig<A, 8, true>(p, g, c, lds);
-            shared_raw[threadIdx.x] = mine;
+            copy_contig<A, 8, true, XB>(p, g, c, lds);
+            stage_twiddles();
             __syncthreads();
             rb.load_lds(x, lds);
-            if (math)
-                radix<A, 4, false>(x, RegTw<A, 4>{w}, c, false);
+            if (math_b) {
+                if constexpr (SHARED_B)
+                    radix<A, 4, false>(x, LdsTw<A>{set_b, c}, c, false);
+                else
+                    radix<A, 4, false>(x, RegTw<A, 4>{w}, c, false);
+            }
             rb.store_lds(x, lds);
         } else {
             rb.load_global(x, p, g, c);
-            shared_raw[threadIdx.x] = mine;
-            if (threadIdx.x < 16)
-                uniform_raw[threadIdx.x] = uni;
+            stage_twiddles();
             __syncthreads();
-            if (math)
-                radix<A, 4, false>(x, LdsTw<A>{shared_sets + ((threadIdx.x >> 4) << 4), c}, c, false);
+            if (math_b)
+                radix<A, 4, false>(x, LdsTw<A>{set_b, c}, c, false);
             rb.store_lds(x, lds);
         }
         __syncthreads();
         ra.load_lds(x, lds);
-        if (math)
-            radix<A, 4, false>(x, LdsTw<A>{CONTIG ? shared_sets + (ra.sigma << 4) : uniform_set, c}, c, scale);
+        if (math_a)
+            radix<A, 4, false>(x, LdsTw<A>{set_a, c}, c, scale);
         ra.store_global(x, p, g);
     }
 }
 
-template <class A, bool FWD, bool CONTIG, int K1, int K2>
+template <class A, bool FWD, bool CONTIG, int K1, int K2, bool XB = false>
 __global__ __launch_bounds__(THREADS, 4) void pass_kernel(PassParams p, typename A::Ctx c)
 {
     constexpr int K = K1 + K2;
@@ -549,8 +611,8 @@ __global__ __launch_bounds__(THREADS, 4) void pass_kernel(PassParams p, typename
     const TileGeom<K> g(p, blockIdx.x);
 
     if constexpr (K1 == 4 && K2 == 4) {
-        __shared__ __attribute__((aligned(16))) typename A::TwElem ldstw[256 + 16];
-        pass_8<A, FWD, CONTIG>(p, g, c, lds, ldstw);
+        __shared__ __attribute__((aligned(16))) typename A::TwElem ldstw[LDSTW_ELEMS];
+        pass_8<A, FWD, CONTIG, XB>(p, g, c, lds, ldstw);
     } else if constexpr (CONTIG) {
         copy_contig<A, K, true>(p, g, c, lds);
         __syncthreads();

@@ -91,10 +91,10 @@ std::vector<PassDesc> make_passes(uint32_t logn)
     return out;
 }
 
-template <class A, bool FWD, bool CONTIG, int K1, int K2>
+template <class A, bool FWD, bool CONTIG, int K1, int K2, bool XB = false>
 hipError_t launch_one(const PassParams& p, const typename A::Ctx& c, unsigned grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((pass_kernel<A, FWD, CONTIG, K1, K2>), dim3(grid), dim3(THREADS), 0, s, p, c);
+    hipLaunchKernelGGL((pass_kernel<A, FWD, CONTIG, K1, K2, XB>), dim3(grid), dim3(THREADS), 0, s, p, c);
     return hipGetLastError();
 }
 
@@ -102,8 +102,9 @@ template <class A, bool FWD>
 hipError_t launch_shape(const PassDesc& d, const PassParams& p, const typename A::Ctx& c, unsigned grid,
                         hipStream_t s)
 {
-    const int key = (d.contig ? 100 : 0) + d.k1 * 10 + d.k2;
+    const int key = ((p.flags & PASS_CROSS_BATCH) ? 1000 : 0) + (d.contig ? 100 : 0) + d.k1 * 10 + d.k2;
     switch (key) {
+    case 1144: return launch_one<A, FWD, true, 4, 4, true>(p, c, grid, s);
     case 120: return launch_one<A, FWD, true, 2, 0>(p, c, grid, s);
     case 140: return launch_one<A, FWD, true, 4, 0>(p, c, grid, s);
     case 142: return launch_one<A, FWD, true, 4, 2>(p, c, grid, s);
@@ -139,9 +140,17 @@ int launch_pass(const nttx_plan* plan, int slot, const PassDesc& d, PassParams p
         return fail(NTTX_EINVAL, "element count is out of range for one launch");
     p.tw = fwd ? plan->d_fwd[slot] : plan->d_inv[slot];
     p.tw_perm = fwd ? plan->d_fwd_perm[slot] : plan->d_inv_perm[slot];
-    static const bool no_math = std::getenv("NTTX_DEBUG_NO_MATH") != nullptr;
-    if (no_math)
-        p.flags |= PASS_DEBUG_NO_MATH;
+    static const uint32_t no_math = [] {
+        const char* e = std::getenv("NTTX_DEBUG_NO_MATH");
+        if (!e)
+            return 0u;
+        return e[0] == 'A' ? (uint32_t)PASS_DEBUG_NO_MATH_A : e[0] == 'B' ? (uint32_t)PASS_DEBUG_NO_MATH_B
+                                                                          : (uint32_t)PASS_DEBUG_NO_MATH;
+    }();
+    p.flags |= no_math;
+    static const bool no_finish = std::getenv("NTTX_DEBUG_NO_FINISH") != nullptr;
+    if (no_finish)
+        p.flags &= ~PASS_FINISH;
     static const bool no_tw = std::getenv("NTTX_DEBUG_NO_TW") != nullptr;
     if (no_tw)
         p.flags |= PASS_DEBUG_NO_TW;
@@ -171,27 +180,39 @@ uint32_t pass_flags(const PassDesc& d, size_t fi, size_t np, bool fwd)
 }
 
 // Enqueues the passes of one transform direction for `batch` vectors at dptr.
+//
+// The pass that holds the last eight stages runs on cross-batch tiles (the same 256-element block
+// of 16 consecutive transforms, so a workgroup shares its twiddles) for the largest multiple of 16
+// transforms, and on plain contiguous tiles for the rest of the batch.
 int enqueue_passes(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream,
                    int only_pass)
 {
-    const uint64_t total = (uint64_t)batch << plan->logn;
-    const uint64_t tiles = (total + TILE - 1) / TILE;
+    static const bool no_xb = std::getenv("NTTX_NO_CROSS_BATCH") != nullptr;
     const size_t np = plan->passes.size();
     for (size_t i = 0; i < np; i++) {
         if (only_pass >= 0 && (size_t)only_pass != i)
             continue;
         const size_t fi = fwd ? i : np - 1 - i;
         const PassDesc& d = plan->passes[fi];
-        PassParams p{};
-        p.data = dptr;
-        p.nblocks_total = (uint64_t)batch << d.s0;
-        p.block_base = 0;
-        p.logB = plan->logn - d.s0;
-        p.s0 = d.s0;
-        p.flags = pass_flags(d, fi, np, fwd);
-        int rc = launch_pass(plan, slot, d, p, tiles, fwd, stream);
-        if (rc != NTTX_OK)
-            return rc;
+        const bool xb_shape = d.contig && d.k1 == 4 && d.k2 == 4 && !no_xb;
+        const size_t xb_batch = xb_shape ? batch & ~(size_t)15 : 0;
+        for (int part = 0; part < 2; part++) {
+            const size_t first = part == 0 ? 0 : xb_batch;
+            const size_t count = part == 0 ? xb_batch : batch - xb_batch;
+            if (count == 0)
+                continue;
+            const uint64_t total = (uint64_t)count << plan->logn;
+            PassParams p{};
+            p.data = dptr + ((uint64_t)first << plan->logn);
+            p.nblocks_total = (uint64_t)count << d.s0;
+            p.block_base = 0;
+            p.logB = plan->logn - d.s0;
+            p.s0 = d.s0;
+            p.flags = pass_flags(d, fi, np, fwd) | (part == 0 ? (uint32_t)PASS_CROSS_BATCH : 0u);
+            int rc = launch_pass(plan, slot, d, p, (total + TILE - 1) / TILE, fwd, stream);
+            if (rc != NTTX_OK)
+                return rc;
+        }
     }
     return NTTX_OK;
 }
