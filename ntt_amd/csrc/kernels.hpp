@@ -208,11 +208,10 @@ __device__ __forceinline__ uint32_t lds_addr(uint32_t sigma, uint32_t r)
 }
 
 // Geometry of one tile, shared by all rounds of a pass.
-template <int K>
+template <int K, bool XB = false>
 struct TileGeom {
     uint32_t logB, logT, logCw, lognblk, logtpb, s0;
     uint64_t tile, nblocks_total, block_base;
-    bool cross_batch;
 
     __device__ __forceinline__ TileGeom(const PassParams& p, uint64_t tile_)
     {
@@ -226,7 +225,6 @@ struct TileGeom {
         tile = tile_;
         nblocks_total = p.nblocks_total;
         block_base = p.block_base;
-        cross_batch = p.flags & PASS_CROSS_BATCH;
     }
     // Block (of 2^logB elements, counted over the whole buffer) that sub-transform sigma belongs to.
     // Ordinarily a tile takes consecutive blocks.  A cross-batch tile (CONTIG, K = 8: blocks are
@@ -234,7 +232,7 @@ struct TileGeom {
     // all its sub-transforms use the same twiddles.
     __device__ __forceinline__ uint64_t block_of(uint32_t sigma) const
     {
-        if (cross_batch)
+        if (XB)
             return ((((tile >> s0) << 4) + sigma) << s0) + (tile & ((1ull << s0) - 1));
         return ((tile >> logtpb) << lognblk) + (sigma >> logCw);
     }
@@ -258,8 +256,9 @@ struct TileGeom {
 // One register round of a pass for one group of 2^KR registers.  ROUND_A covers the K1 stages
 // with the larger strides (elements rlow + (i << K2)), round B the K2 stages with the smaller
 // ones (elements (rhigh << K2) + i).
-template <class A, bool CONTIG, int K1, int K2, bool ROUND_A>
+template <class A, bool CONTIG, int K1, int K2, bool ROUND_A, bool XB = false>
 struct Round {
+    using Geom = TileGeom<K1 + K2, XB>;
     static constexpr int K = K1 + K2;
     static constexpr int KR = ROUND_A ? K1 : K2; // stages in this round
     static constexpr int KO = ROUND_A ? K2 : K1; // stages in the other round
@@ -272,7 +271,7 @@ struct Round {
     bool ok;
     uint64_t P; // twiddle base of this group's KR stages
 
-    __device__ __forceinline__ Round(const TileGeom<K>& g, int gamma)
+    __device__ __forceinline__ Round(const Geom& g, int gamma)
     {
         const uint32_t slot = gamma * THREADS + threadIdx.x;
         uint32_t rpart;
@@ -289,7 +288,7 @@ struct Round {
         P = ok ? (ROUND_A ? base : ((base << K1) + rpart)) : 1;
     }
 
-    __device__ __forceinline__ void load_global(uint64_t (&x)[M], const PassParams& p, const TileGeom<K>& g,
+    __device__ __forceinline__ void load_global(uint64_t (&x)[M], const PassParams& p, const Geom& g,
                                                 const typename A::Ctx& c) const
     {
         if (ok) {
@@ -307,7 +306,7 @@ struct Round {
             condition_all<A, M>(x, c);
     }
     __device__ __forceinline__ void store_global(const uint64_t (&x)[M], const PassParams& p,
-                                                 const TileGeom<K>& g) const
+                                                 const Geom& g) const
     {
         if (ok) {
             uint64_t* dst = p.data + g.gidx(sigma, r0);
@@ -382,23 +381,36 @@ __device__ __forceinline__ void wave_sync()
 // elements (cross-batch tile) instead of one run of 4096.
 // PER_WAVE: every wave moves its own quarter of the tile (elements [1024 w, 1024 w + 1024)).
 template <class A, int K, bool TO_LDS, bool XB = false, bool PER_WAVE = false>
-__device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<K>& g, const typename A::Ctx& c,
+__device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<K, XB>& g, const typename A::Ctx& c,
                                             uint64_t* lds)
 {
     const uint64_t total = p.nblocks_total << p.logB;
     const uint64_t base = g.tile << TILE_LOG;
-    // element handled in step i
+    // cross-batch tile: run sigma (256 elements of transform 16 tau + sigma) starts n elements
+    // after run sigma - 1; everything but the lane offset is wave-uniform
+    const uint64_t tau16 = (g.tile >> g.s0) << 4;
+    const uint64_t run0 = (((tau16 << g.s0) + (g.tile & ((1ull << g.s0) - 1))) << K);
+    const uint64_t run_stride = 1ull << (g.s0 + K);
+    const uint64_t runs_valid = (p.nblocks_total >> g.s0) - tau16; // transforms left from the tile's first
+    // element handled in step i.  With K = 8 its run f >> 8 is made explicitly wave-uniform so
+    // that run addresses and bounds checks stay in scalar registers.
     auto elem = [](int i) -> uint32_t {
-        if (PER_WAVE)
-            return (threadIdx.x >> 6) * (TILE / 4) + 2 * (i * 64 + (threadIdx.x & 63));
+        if (PER_WAVE) {
+            const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            return wave * (TILE / 4) + i * 128 + 2 * (threadIdx.x & 63);
+        }
+        if (K == 8) {
+            const uint32_t half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
+            return (2 * i + half) * 256 + 2 * (threadIdx.x & 127);
+        }
         return 2 * (i * THREADS + threadIdx.x);
     };
     // element f of the tile: its address and whether it exists (f is even; pairs never straddle runs)
     auto where = [&](uint32_t f, uint64_t*& ptr) -> bool {
         if (XB) {
-            const uint32_t sigma = f >> K;
-            ptr = p.data + g.gidx(sigma, f & ((1u << K) - 1));
-            return g.valid(sigma);
+            const uint32_t sigma = __builtin_amdgcn_readfirstlane(f >> K);
+            ptr = p.data + run0 + sigma * run_stride + (f & ((1u << K) - 1));
+            return sigma < runs_valid;
         }
         ptr = p.data + base + f;
         return base + f < total; // total is a multiple of 4 (n >= 4)
@@ -481,13 +493,13 @@ constexpr int TW_SET_STRIDE = 17;
 constexpr int LDSTW_ELEMS = 16 * TW_SET_STRIDE + 16;
 
 template <class A, bool FWD, bool CONTIG, bool XB>
-__device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8>& g, const typename A::Ctx& c,
+__device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8, XB>& g, const typename A::Ctx& c,
                                        uint64_t* lds, typename A::TwElem* ldstw)
 {
     static_assert(CONTIG || !XB, "cross-batch tiles are CONTIG tiles");
     constexpr bool SHARED_B = !CONTIG || XB; // round B reads shared sets, round A the single set
-    using RA = Round<A, CONTIG, 4, 4, true>;
-    using RB = Round<A, CONTIG, 4, 4, false>;
+    using RA = Round<A, CONTIG, 4, 4, true, XB>;
+    using RB = Round<A, CONTIG, 4, 4, false, XB>;
     using TwElem = typename A::TwElem;
     const TwElem* tw = static_cast<const TwElem*>(p.tw);
     const TwElem* twp = static_cast<const TwElem*>(p.tw_perm);
@@ -608,7 +620,7 @@ __global__ __launch_bounds__(THREADS, 4) void pass_kernel(PassParams p, typename
 {
     constexpr int K = K1 + K2;
     __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
-    const TileGeom<K> g(p, blockIdx.x);
+    const TileGeom<K, XB> g(p, blockIdx.x);
 
     if constexpr (K1 == 4 && K2 == 4) {
         __shared__ __attribute__((aligned(16))) typename A::TwElem ldstw[LDSTW_ELEMS];

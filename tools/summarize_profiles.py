@@ -13,7 +13,7 @@ shutil.copy(src + "/bench.json", "profiles/%s_bench.json" % tag)
 
 
 def short(name):
-    m = re.search(r"pass_kernel<nttx::(\w+(?:<\w+>)?), (\w+), (\w+), (\d), (\d)>", name)
+    m = re.search(r"pass_kernel<nttx::(\w+(?:<\w+>)?), (\w+), (\w+), (\d), (\d)(?:, (\w+))?>", name)
     if not m:
         return None
     return (m.group(1), "fwd" if m.group(2) == "true" else "bwd", "contig" if m.group(3) == "true" else "strided",
