@@ -26,6 +26,12 @@ extern "C" {
     pub fn nttx_backward_host(plan: *const NttxPlan, data: *mut u64, batch: usize) -> c_int;
     pub fn nttx_forward_device(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, stream: *mut c_void) -> c_int;
     pub fn nttx_backward_device(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, stream: *mut c_void) -> c_int;
+    pub fn nttx_forward_distributed(plan: *const NttxPlan, host_data: *mut u64, n_shards: c_int) -> c_int;
+    pub fn nttx_backward_distributed(plan: *const NttxPlan, host_data: *mut u64, n_shards: c_int) -> c_int;
+    pub fn nttx_shard_geometry(plan: *const NttxPlan, n_shards: c_int, local_elems: *mut u64, rows: *mut u64,
+                               cols: *mut u64, rows_per_peer: *mut u64) -> c_int;
+    pub fn nttx_shard_phase_device(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, dir: c_int, phase: c_int,
+                                   shard: c_int, n_shards: c_int, stream: *mut c_void) -> c_int;
     pub fn nttx_last_error() -> *const c_char;
 }
 
