@@ -78,6 +78,17 @@ inline void run(const nttx_plan* plan, uint64_t n, void* x, size_t len, bool for
                   : nttx_backward_host(plan, static_cast<uint64_t*>(x), 1));
 }
 
+// Same transform computed by n_shards shards over the plan's devices (one exchange between them);
+// n_shards = 0: one shard per device.  No counterpart in the reference, which runs any length in
+// one loop nest; results are identical.
+inline void run_distributed(const nttx_plan* plan, uint64_t n, void* x, size_t len, bool forward, int n_shards)
+{
+    if (len != n)
+        throw Panic("slice length does not match the table size");
+    check(forward ? nttx_forward_distributed(plan, static_cast<uint64_t*>(x), n_shards)
+                  : nttx_backward_distributed(plan, static_cast<uint64_t*>(x), n_shards));
+}
+
 } // namespace detail
 
 template <class O>
@@ -132,6 +143,15 @@ class Table<uint64_t> : public DFT<uint64_t> {
     void forward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true); }
     template <bool LAZY>
     void backward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false); }
+
+    void forward_inplace_distributed(uint64_t* a, size_t len, int n_shards = 0) const
+    {
+        detail::run_distributed(plan_.get(), n_, a, len, true, n_shards);
+    }
+    void backward_inplace_distributed(uint64_t* a, size_t len, int n_shards = 0) const
+    {
+        detail::run_distributed(plan_.get(), n_, a, len, false, n_shards);
+    }
 
     const nttx_plan* plan() const { return plan_.get(); }
 
@@ -191,6 +211,15 @@ class TableAVX2 : public DFT<int64_t> {
     void forward_inplace_core(int64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true); }   // :108
     template <bool LAZY>
     void backward_inplace_core(int64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false); } // :281
+
+    void forward_inplace_distributed(int64_t* a, size_t len, int n_shards = 0) const
+    {
+        detail::run_distributed(plan_.get(), n_, a, len, true, n_shards);
+    }
+    void backward_inplace_distributed(int64_t* a, size_t len, int n_shards = 0) const
+    {
+        detail::run_distributed(plan_.get(), n_, a, len, false, n_shards);
+    }
 
     const nttx_plan* plan() const { return plan_.get(); }
 
@@ -253,6 +282,15 @@ class TableGoldilock<uint64_t> : public DFT<uint64_t> {
     void forward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true); }   // :81
     template <bool LAZY>
     void backward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false); } // :128
+
+    void forward_inplace_distributed(uint64_t* a, size_t len, int n_shards = 0) const
+    {
+        detail::run_distributed(plan_.get(), n_, a, len, true, n_shards);
+    }
+    void backward_inplace_distributed(uint64_t* a, size_t len, int n_shards = 0) const
+    {
+        detail::run_distributed(plan_.get(), n_, a, len, false, n_shards);
+    }
 
     const nttx_plan* plan() const { return plan_.get(); }
 

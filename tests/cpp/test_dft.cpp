@@ -124,9 +124,47 @@ static void panics()
     CHECK(threw);
 }
 
+// One transform computed by several shards must equal the unsplit transform (all three tables).
+static void split_equals_unsplit()
+{
+    auto table = Table<uint64_t>::new_();
+    auto a = random_below(table.q, 1 << 16, 7), b = a;
+    table.forward_inplace(a);
+    table.forward_inplace_distributed(b.data(), b.size(), 8);
+    CHECK(a == b);
+    table.backward_inplace_distributed(b.data(), b.size(), 4);
+    table.backward_inplace(a);
+    CHECK(a == b);
+
+    auto gl = TableGoldilock<uint64_t>::new_();
+    auto c = random_below(gl.q, 1 << 16, 8), d = c;
+    gl.forward_inplace(c);
+    gl.forward_inplace_distributed(d.data(), d.size(), 2);
+    CHECK(c == d);
+
+    auto avx = TableAVX2::new_();
+    std::vector<int64_t> e(1 << 16), f;
+    auto raw = random_below((uint64_t)avx.q, 1 << 16, 9);
+    for (size_t i = 0; i < e.size(); i++)
+        e[i] = (int64_t)raw[i];
+    f = e;
+    avx.forward_inplace(e);
+    avx.forward_inplace_distributed(f.data(), f.size(), 8);
+    CHECK(e == f);
+
+    bool threw = false;
+    try {
+        table.forward_inplace_distributed(b.data(), b.size(), 3);
+    } catch (const ntt::Panic&) {
+        threw = true;
+    }
+    CHECK(threw);
+}
+
 int main()
 {
     utils_tests();
+    split_equals_unsplit();
     base_version();
     avx_correctness();
     goldilock_correctness();
