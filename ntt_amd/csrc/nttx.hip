@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -54,6 +56,15 @@ struct nttx_plan {
     std::vector<void*> d_fwd, d_inv;           // per device: tables in the reference's index order
     std::vector<void*> d_fwd_perm, d_inv_perm; // per device: last four stages regrouped (permuted_index)
     std::vector<PassDesc> passes;        // forward order
+    // Host-slice calls (nttx_*_host) keep one stream and one staging buffer per device between
+    // calls, so a single-vector call pays two copies and the kernels, not an allocation.
+    struct HostSlot {
+        std::mutex lock; // host-slice calls on one device run one at a time
+        hipStream_t stream = nullptr;
+        void* buf = nullptr;
+        size_t cap = 0;
+    };
+    mutable std::vector<std::unique_ptr<HostSlot>> host_slots;
 };
 
 namespace {
@@ -451,6 +462,9 @@ int enqueue(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool 
     return NTTX_OK;
 }
 
+// Staging buffers up to this size stay allocated between host-slice calls.
+constexpr size_t HOST_SLOT_KEEP_BYTES = 256ull << 20;
+
 int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd)
 {
     if (!plan)
@@ -462,8 +476,10 @@ int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd)
     const size_t ndev = plan->devices.size();
     const size_t per = (batch + ndev - 1) / ndev;
     struct Work {
+        nttx_plan::HostSlot* slot = nullptr;
+        std::unique_lock<std::mutex> guard;
         uint64_t* d = nullptr;
-        hipStream_t s = nullptr;
+        bool own = false; // d was allocated for this call (too large to keep)
         size_t first = 0, count = 0;
     };
     std::vector<Work> work(ndev);
@@ -480,32 +496,47 @@ int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd)
             w.count = std::min(per, batch - w.first);
             const size_t bytes = (w.count << plan->logn) * sizeof(uint64_t);
             HIP_TRY(hipSetDevice(plan->devices[i]));
-            HIP_TRY(hipStreamCreateWithFlags(&w.s, hipStreamNonBlocking));
-            HIP_TRY(hipMalloc(&w.d, bytes));
-            HIP_TRY(hipMemcpyAsync(w.d, data + (w.first << plan->logn), bytes, hipMemcpyHostToDevice, w.s));
-            int r = enqueue(plan, (int)i, w.d, w.count, fwd, w.s);
+            w.slot = plan->host_slots[i].get();
+            w.guard = std::unique_lock<std::mutex>(w.slot->lock);
+            if (!w.slot->stream)
+                HIP_TRY(hipStreamCreateWithFlags(&w.slot->stream, hipStreamNonBlocking));
+            if (bytes <= w.slot->cap) {
+                w.d = static_cast<uint64_t*>(w.slot->buf);
+            } else if (bytes <= HOST_SLOT_KEEP_BYTES) {
+                if (w.slot->buf)
+                    (void)hipFree(w.slot->buf);
+                w.slot->buf = nullptr;
+                w.slot->cap = 0;
+                HIP_TRY(hipMalloc(&w.slot->buf, bytes));
+                w.slot->cap = bytes;
+                w.d = static_cast<uint64_t*>(w.slot->buf);
+            } else {
+                HIP_TRY(hipMalloc(&w.d, bytes));
+                w.own = true;
+            }
+            hipStream_t st = w.slot->stream;
+            HIP_TRY(hipMemcpyAsync(w.d, data + (w.first << plan->logn), bytes, hipMemcpyHostToDevice, st));
+            int r = enqueue(plan, (int)i, w.d, w.count, fwd, st);
             if (r != NTTX_OK)
                 return r;
-            HIP_TRY(hipMemcpyAsync(data + (w.first << plan->logn), w.d, bytes, hipMemcpyDeviceToHost, w.s));
+            HIP_TRY(hipMemcpyAsync(data + (w.first << plan->logn), w.d, bytes, hipMemcpyDeviceToHost, st));
         }
         for (size_t i = 0; i < ndev; i++) {
-            if (!work[i].s)
+            if (!work[i].slot)
                 continue;
             HIP_TRY(hipSetDevice(plan->devices[i]));
-            HIP_TRY(hipStreamSynchronize(work[i].s));
+            HIP_TRY(hipStreamSynchronize(work[i].slot->stream));
         }
         return NTTX_OK;
     };
     rc = body();
     for (size_t i = 0; i < ndev; i++) {
-        if (!work[i].s && !work[i].d)
+        if (!work[i].slot)
             continue;
         (void)hipSetDevice(plan->devices[i]);
-        if (work[i].s) {
-            (void)hipStreamSynchronize(work[i].s);
-            (void)hipStreamDestroy(work[i].s);
-        }
-        if (work[i].d)
+        if (work[i].slot->stream)
+            (void)hipStreamSynchronize(work[i].slot->stream);
+        if (work[i].own && work[i].d)
             (void)hipFree(work[i].d);
     }
     (void)hipSetDevice(prev);
@@ -565,6 +596,9 @@ int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
         std::memcpy(&perm_inv[j * esz], src_inv + i * esz, esz);
     }
     const size_t nd = plan->devices.size();
+    plan->host_slots.clear();
+    for (size_t i = 0; i < nd; i++)
+        plan->host_slots.emplace_back(new nttx_plan::HostSlot);
     plan->d_fwd.assign(nd, nullptr);
     plan->d_inv.assign(nd, nullptr);
     plan->d_fwd_perm.assign(nd, nullptr);
@@ -719,6 +753,12 @@ void nttx_plan_destroy(nttx_plan* plan)
             (void)hipFree(plan->d_fwd_perm[i]);
         if (i < plan->d_inv_perm.size() && plan->d_inv_perm[i])
             (void)hipFree(plan->d_inv_perm[i]);
+        if (i < plan->host_slots.size() && plan->host_slots[i]) {
+            if (plan->host_slots[i]->stream)
+                (void)hipStreamDestroy(plan->host_slots[i]->stream);
+            if (plan->host_slots[i]->buf)
+                (void)hipFree(plan->host_slots[i]->buf);
+        }
     }
     (void)hipSetDevice(prev);
     delete plan;
