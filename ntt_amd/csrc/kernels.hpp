@@ -461,9 +461,11 @@ __host__ __device__ inline uint64_t permuted_index(uint64_t idx, uint32_t logn)
 {
     if (logn < 8 || idx < (1ull << (logn - 4)))
         return idx;
-    uint32_t top = 63;
-    while (!((idx >> top) & 1))
-        top--;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t top = 63 - __clzll((long long)idx);
+#else
+    const uint32_t top = 63 - (uint32_t)__builtin_clzll(idx);
+#endif
     const uint32_t v = top - (logn - 5);            // 1..4
     const uint64_t base = 1ull << top;
     const uint64_t off = idx - base;                 // (beta * 16 + rhigh) << (v-1) | i

@@ -27,6 +27,32 @@ inline uint32_t ilog2(uint64_t n)
 
 // ntt.rs:90-120 followed by with_precomputes (ntt.rs:239-261).  The i64 instance used by
 // TableAVX2 (ntt_avx2.rs:74-105, 592-613) produces the same bit patterns.
+// out[bit_reverse(i)] = one * g^i for i < 2^log_n, the table the reference fills with a serial
+// chain tmp = tmp * g stored at bit_reverse(i, log_n) (ntt.rs:251-258, ntt_goldilock.rs:205-211).
+// The products are canonical residues, so the order of multiplication does not change them: the
+// table is built by doubling instead -- out[2^k + j] = out[j] * g^(n / 2^(k+1)) for j < 2^k, because
+// bit_reverse(2^k + j) = bit_reverse(j) + n / 2^(k+1) -- which walks memory sequentially (the chain
+// scatters its 2^28 writes of the largest table over 2 GiB).
+// Odd log_n: the reference's bit_reverse (utils.rs:14-17) is not a reversal and indexes out of bounds.
+template <class Mul>
+inline void fill_bit_reversed_powers(std::vector<uint64_t>& out, uint32_t log_n, uint64_t one, uint64_t g, Mul mul)
+{
+    if (log_n % 2 != 0)
+        throw Panic("index out of bounds: bit_reverse is only a reversal for even log2(n)");
+    std::vector<uint64_t> step(log_n ? log_n : 1); // step[k] = g^(n / 2^(k+1))
+    uint64_t sq = g;
+    for (uint32_t k = log_n; k-- > 0;) {
+        step[k] = sq;
+        sq = mul(sq, sq);
+    }
+    out[0] = one;
+    for (uint32_t k = 0; k < log_n; k++) {
+        const uint64_t half = 1ull << k, s = step[k];
+        for (uint64_t j = 0; j < half; j++)
+            out[half + j] = mul(out[j], s);
+    }
+}
+
 inline MontgomeryTables build_montgomery_tables(uint64_t modulus, uint64_t root, uint64_t n)
 {
     using utils::i128;
@@ -47,15 +73,11 @@ inline MontgomeryTables build_montgomery_tables(uint64_t modulus, uint64_t root,
     const uint32_t log_n = ilog2(n);
     t.powers_psi_bo.assign(n, 0);
     t.powers_psi_inv_bo.assign(n, 0);
-    for (uint64_t i = 0; i < n; i++) {
-        const uint64_t reversed_index = utils::bit_reverse(i, log_n);
-        if (reversed_index >= n) // Vec index out of bounds in the reference (odd log2 n)
-            throw Panic("index out of bounds: bit_reverse is only a reversal for even log2(n)");
-        t.powers_psi_bo[reversed_index] = tmp_psi;
-        t.powers_psi_inv_bo[reversed_index] = tmp_psi_inv;
-        tmp_psi = t.montgomery.mul(tmp_psi, psi_montgomery);
-        tmp_psi_inv = t.montgomery.mul(tmp_psi_inv, t.psi_inv_montgomery);
-    }
+    const auto& M = t.montgomery;
+    fill_bit_reversed_powers(t.powers_psi_bo, log_n, tmp_psi, psi_montgomery,
+                             [&](uint64_t a, uint64_t b) { return M.mul(a, b); });
+    fill_bit_reversed_powers(t.powers_psi_inv_bo, log_n, tmp_psi_inv, t.psi_inv_montgomery,
+                             [&](uint64_t a, uint64_t b) { return M.mul(a, b); });
     return t;
 }
 
@@ -98,19 +120,11 @@ inline GoldilocksTables build_goldilocks_tables(uint64_t psi, uint64_t n)
         throw Panic("n must be a power of two dividing q - 1");
     GoldilocksTables t{GOLDILOCKS_Q - (GOLDILOCKS_Q - 1) / n, {}, {}};
     const uint64_t psi_inv = utils::mod_exp_u64(psi, GOLDILOCKS_Q - 2, GOLDILOCKS_Q);
-    uint64_t tmp_psi = 1, tmp_psi_inv = 1;
     const uint32_t log_n = ilog2(n);
     t.powers_psi_bo.assign(n, 0);
     t.powers_psi_inv_bo.assign(n, 0);
-    for (uint64_t i = 0; i < n; i++) {
-        const uint64_t reversed_index = utils::bit_reverse(i, log_n);
-        if (reversed_index >= n)
-            throw Panic("index out of bounds: bit_reverse is only a reversal for even log2(n)");
-        t.powers_psi_bo[reversed_index] = tmp_psi;
-        t.powers_psi_inv_bo[reversed_index] = tmp_psi_inv;
-        tmp_psi = goldilocks_mul_reduce(tmp_psi, psi);
-        tmp_psi_inv = goldilocks_mul_reduce(tmp_psi_inv, psi_inv);
-    }
+    fill_bit_reversed_powers(t.powers_psi_bo, log_n, 1, psi, goldilocks_mul_reduce);
+    fill_bit_reversed_powers(t.powers_psi_inv_bo, log_n, 1, psi_inv, goldilocks_mul_reduce);
     return t;
 }
 
