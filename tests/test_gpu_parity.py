@@ -350,3 +350,79 @@ def test_baseline_sizes_device_resident(amd, workload):
     gpu.backward_inplace(data)
     torch.cuda.synchronize()
     assert torch.equal(data, original)
+
+
+def test_abi_argument_checks(amd):
+    """Status codes of the C ABI for arguments the Python layer normally screens."""
+    import ctypes as C
+
+    import torch
+    from ntt_amd import _lib
+    lib = _lib.lib
+    t = amd.Table.from_prime_and_root(Q61, psi61_for(1 << 12), 1 << 12)
+    buf = torch.zeros(2 * (1 << 12), dtype=torch.int64, device="cuda")
+    assert lib.nttx_forward_device(None, 0, buf.data_ptr(), 1, None) == _lib.NTTX_EINVAL
+    assert lib.nttx_forward_device(t._plan, 0, None, 1, None) == _lib.NTTX_EINVAL
+    assert lib.nttx_forward_device(t._plan, 0, buf.data_ptr() + 8, 1, None) == _lib.NTTX_EINVAL   # 16-byte alignment
+    assert b"aligned" in lib.nttx_last_error()
+    assert lib.nttx_forward_device(t._plan, 5, buf.data_ptr(), 1, None) == _lib.NTTX_ENODEV       # not a plan device
+    assert lib.nttx_forward_device(t._plan, 0, buf.data_ptr(), 0, None) == _lib.NTTX_OK           # empty batch
+    assert lib.nttx_forward_host(t._plan, None, 1) == _lib.NTTX_EINVAL
+    assert lib.nttx_forward_host(t._plan, None, 0) == _lib.NTTX_OK
+    assert lib.nttx_run_pass_device(t._plan, 0, buf.data_ptr(), 1, 0, 7, None) == _lib.NTTX_EINVAL
+    assert lib.nttx_shard_phase_device(t._plan, 0, buf.data_ptr(), 0, 2, 0, 1, None) == _lib.NTTX_EINVAL
+    plan = C.c_void_p()
+    dev = (C.c_int * 2)(0, 0)
+    assert lib.nttx_plan_create_from_root(0, Q61, psi61_for(16), 16, dev, 2, C.byref(plan)) == _lib.NTTX_EINVAL  # listed twice
+    dev = (C.c_int * 1)(99)
+    assert lib.nttx_plan_create_from_root(0, Q61, psi61_for(16), 16, dev, 1, C.byref(plan)) == _lib.NTTX_ENODEV
+    assert lib.nttx_plan_create_from_root(7, Q61, psi61_for(16), 16, None, 0, C.byref(plan)) == _lib.NTTX_EINVAL
+    assert not plan.value
+
+
+def test_one_plan_many_host_threads(amd):
+    """A plan is immutable and shared (`&self` methods, auto Send + Sync in the reference): calls from
+    several host threads on their own slices -- host and device entry points mixed -- must not disturb
+    each other."""
+    import threading
+
+    import torch
+    n = 1 << 16
+    gpu, ref = amd.Table.new(), orc.Table.new()
+    inputs = [orc.splitmix_residues(Q61, n, 700 + i) for i in range(8)]
+    want = []
+    for a in inputs:
+        w = a.copy()
+        ref.forward_inplace(w)
+        want.append(w)
+    got = [None] * len(inputs)
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                if i % 2 == 0:
+                    a = inputs[i].copy()
+                    gpu.forward_inplace(a)
+                    b = a.copy()
+                    gpu.backward_inplace(b)
+                    assert np.array_equal(b, inputs[i])
+                else:
+                    s = torch.cuda.Stream()
+                    with torch.cuda.stream(s):
+                        d = torch.from_numpy(inputs[i].view(np.int64)).cuda()
+                        gpu.forward_inplace(d)
+                        s.synchronize()
+                        a = d.cpu().numpy().view(np.uint64).copy()
+                got[i] = a
+        except Exception as e:  # surfaced below
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(inputs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for i in range(len(inputs)):
+        assert np.array_equal(got[i], want[i]), i
