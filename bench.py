@@ -169,11 +169,22 @@ def main():
     if os.path.exists(tpath) and batch == default_batch:
         with open(tpath) as fh:
             traffic = json.load(fh).get(dom["name"])
+    # second bound: integer VALU.  Wave-level VALU instructions per launch of that kernel from the
+    # PMC pass recorded under profiles/ (SQ_INSTS_VALU); a wave64 instruction occupies its SIMD's
+    # 16 lanes for at least 4 cycles, and the chip has 1024 SIMDs at 2.4 GHz.
+    valu = None
+    vpath = os.path.join(ROOT, "profiles", "valu_%s.json" % args.workload)
+    if os.path.exists(vpath) and batch == default_batch:
+        with open(vpath) as fh:
+            insts = json.load(fh).get(dom["name"])
+        if insts:
+            valu = {"wave_instructions_per_launch": insts,
+                    "issue_utilisation": round(insts * 4 / (dom["avg_ms"] * 1e-3 * 1024 * 2.4e9), 3)}
     roofline = {
         "bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom["avg_ms"], 4),
-        "whole_job_frac": round(frac_job, 4),
+        "whole_job_frac": round(frac_job, 4), "valu": valu,
         "kernels": [{"name": k["name"], "avg_ms": round(k["avg_ms"], 4)} for k in kernels],
     }
 

@@ -1,6 +1,6 @@
 """Turns gpurun_out/<tag> (tools/collect_profiles.sh) into the committed summaries under profiles/:
 <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <tag>_pmc.txt (mean counter per kernel),
-and traffic_<workload>.json (HBM bytes per launch: FETCH_SIZE KB x 1024 x 2 -- gfx950 tallies a
+traffic_<workload>.json (HBM bytes per launch: FETCH_SIZE KB x 1024 x 2 -- gfx950 tallies a
 128-byte read request as 64 bytes -- plus WRITE_SIZE KB x 1024)."""
 import collections, csv, glob, json, os, re, shutil, sys
 
@@ -35,6 +35,7 @@ with open("profiles/%s_pmc.txt" % tag, "w") as out:
 # traffic per launch, keyed by the pass name bench.py reports ("fwd strided 4+4 stages 1-8")
 bench = json.load(open(src + "/bench.json"))
 traffic = {}
+valu = {}  # wave-level VALU instructions per launch (SQ_INSTS_VALU)
 for kern in bench["roofline"]["kernels"]:
     name = kern["name"]
     d, layout, ks = name.split(" ")[0], name.split(" ")[1], name.split(" ")[2]
@@ -46,5 +47,9 @@ for kern in bench["roofline"]["kernels"]:
     fetch = sum(acc[(k, "FETCH_SIZE")]) / len(acc[(k, "FETCH_SIZE")])
     write = sum(acc[(k, "WRITE_SIZE")]) / len(acc[(k, "WRITE_SIZE")])
     traffic[name] = int(fetch * 1024 * 2 + write * 1024)
+    if (k, "SQ_INSTS_VALU") in acc:
+        valu[name] = int(sum(acc[(k, "SQ_INSTS_VALU")]) / len(acc[(k, "SQ_INSTS_VALU")]))
 json.dump(traffic, open("profiles/traffic_%s.json" % workload, "w"), indent=1)
+json.dump(valu, open("profiles/valu_%s.json" % workload, "w"), indent=1)
 print(json.dumps(traffic, indent=1))
+print(json.dumps(valu, indent=1))
