@@ -102,6 +102,23 @@ int nttx_forward_device(const nttx_plan *plan, int device, void *dptr, size_t ba
 int nttx_backward_device(const nttx_plan *plan, int device, void *dptr, size_t batch, void *hip_stream);
 
 /*
+ * Negacyclic product a <- a * b in Z_q[X]/(X^n + 1) for `batch` pairs of polynomials (batch*n
+ * coefficients each, natural order in and out).  No counterpart in the reference: it is the
+ * composition its callers write around the transforms -- forward_inplace(a), forward_inplace(b)
+ * (ntt.rs:27-29 / ntt_goldilock.rs:21-23), coefficient-wise product mod q, backward_inplace
+ * (ntt.rs:41-43 / ntt_goldilock.rs:35-37) -- with the product fused into the first pass of the
+ * backward transform, so it costs no pass over memory of its own.  The coefficient-wise product
+ * is the canonical residue (for NTTX_GOLDILOCKS: mul_reduce, ntt_goldilock.rs:183-190, which is
+ * canonical even for the value q the forward transform can emit), so the result equals that
+ * composition bit for bit.  Afterwards b holds its forward transform (device entry point; the
+ * host entry point leaves the caller's b untouched).  Passing the same pointer as a and b
+ * squares; partially overlapping operands are rejected.
+ */
+int nttx_negacyclic_mul_host(const nttx_plan *plan, uint64_t *a, const uint64_t *b, size_t batch);
+int nttx_negacyclic_mul_device(const nttx_plan *plan, int device, void *a, void *b, size_t batch,
+                               void *hip_stream);
+
+/*
  * Profiling hooks (no counterpart in the reference).  One forward or backward call issues
  * nttx_pass_count() kernel launches ("passes"); dir = 0 forward, 1 backward, and pass indices
  * follow execution order for that direction.  nttx_pass_describe writes a short name such as

@@ -22,6 +22,8 @@ SYMBOLS = {
     "nttx_backward_host": (C.c_int, [_vp, _vp, _sz]),
     "nttx_forward_device": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp]),
     "nttx_backward_device": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp]),
+    "nttx_negacyclic_mul_host": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "nttx_negacyclic_mul_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _sz, _vp]),
     "nttx_pass_count": (C.c_int, [_vp]),
     "nttx_pass_describe": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, _sz]),
     "nttx_run_pass_device": (C.c_int, [_vp, C.c_int, _vp, _sz, C.c_int, C.c_int, _vp]),

@@ -136,6 +136,7 @@ struct Shoup61Ctx {
     TwPair one;    // (1, floor(2^64 / q)): reduces an arbitrary u64 input
     TwPair scale;  // n^-1 (plain residue) and its quotient
     TwPair scale1; // tw[1] * n^-1 mod q and its quotient (twiddle of inverse stage 1, pre-scaled)
+    uint64_t k;    // q^-1 mod 2^64 (utils.rs:130), for the product of two data words
 };
 
 struct Shoup61 {
@@ -239,6 +240,17 @@ struct Shoup61 {
         return (x >= c.q) ? canon4(mul(x, make(c.one), c), c) : x;
     }
 
+    // a * b * 2^-64 mod q in [0, q) for residues a, b (neither has a precomputed quotient, so this
+    // is REDC as in utils.rs:165-178); the plan folds the factor 2^64 back in with n^-1.
+    static NTTX_HD uint64_t pointwise(uint64_t a, uint64_t b, const Ctx& c)
+    {
+        uint64_t hi, lo;
+        mul_wide(a, b, hi, lo);
+        const uint64_t mq_hi = mul_hi(lo * c.k, c.q);
+        const uint64_t r = hi - mq_hi;
+        return (hi < mq_hi) ? r + c.q : r;
+    }
+
     // [0, 8q) -> [0, q): the canonical value ntt.rs:173-175 ends with.
     static NTTX_HD uint64_t finish(uint64_t x, const Ctx& c) { return canon4(csub(x, c.q4), c); }
 };
@@ -323,6 +335,9 @@ struct Mont {
     {
         return (x >= c.q) ? mul(x, c.r_mod_q, c) : x;
     }
+
+    // a * b * 2^-64 mod q for residues a, b; the plan folds the factor 2^64 back in with n^-1.
+    static NTTX_HD uint64_t pointwise(uint64_t a, uint64_t b, const Ctx& c) { return mul(a, b, c); }
 
     static NTTX_HD uint64_t finish(uint64_t x, const Ctx&) { return x; }
 };
@@ -668,6 +683,8 @@ struct Goldilocks {
 
     static NTTX_HD uint64_t condition_input(uint64_t x, const Ctx&) { return x; }
     static NTTX_HD uint64_t finish(uint64_t x, const Ctx&) { return x; }
+    // mul_reduce (ntt_goldilock.rs:183-190): canonical for any operands, q itself included
+    static NTTX_HD uint64_t pointwise(uint64_t a, uint64_t b, const Ctx&) { return mul_strict(a, b); }
 };
 
 } // namespace nttx

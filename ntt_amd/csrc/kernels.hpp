@@ -36,11 +36,13 @@ enum : uint32_t {
     PASS_DEBUG_NO_TW = 16u,    // profiling aid (NTTX_DEBUG_NO_TW=1, with NO_MATH): skip the twiddle loads too
     PASS_DEBUG_NO_MATH_A = 32u, // profiling aids (NTTX_DEBUG_NO_MATH=A / B): skip one register round of the 8-stage pass
     PASS_DEBUG_NO_MATH_B = 64u,
+    PASS_POINTWISE = 256u,     // first pass of a backward transform: multiply by the vector at data2 first
     PASS_CROSS_BATCH = 128u    // CONTIG 8-stage pass: a tile is the same 256-element block of 16 consecutive transforms
 };
 
 struct PassParams {
     uint64_t* data;
+    const uint64_t* data2;    // PASS_POINTWISE: second operand, same layout as data
     const void* tw;           // device twiddle table of this direction, n entries of Arith::TwElem
     const void* tw_perm;      // same entries with the last four stages regrouped (see permuted_index)
     uint64_t nblocks_total;   // blocks in the buffer: batch << s0, or one shard's share of a split transform
@@ -405,30 +407,42 @@ __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<
         }
         return 2 * (i * THREADS + threadIdx.x);
     };
-    // element f of the tile: its address and whether it exists (f is even; pairs never straddle runs)
-    auto where = [&](uint32_t f, uint64_t*& ptr) -> bool {
+    // element f of the tile: its offset in the buffer and whether it exists (f is even; pairs
+    // never straddle runs)
+    auto where = [&](uint32_t f, uint64_t& off) -> bool {
         if (XB) {
             const uint32_t sigma = __builtin_amdgcn_readfirstlane(f >> K);
-            ptr = p.data + run0 + sigma * run_stride + (f & ((1u << K) - 1));
+            off = run0 + sigma * run_stride + (f & ((1u << K) - 1));
             return sigma < runs_valid;
         }
-        ptr = p.data + base + f;
+        off = base + f;
         return base + f < total; // total is a multiple of 4 (n >= 4)
     };
     if (TO_LDS) {
         uint64_t x[REGS];
 #pragma unroll
         for (int i = 0; i < REGS / 2; i++) {
-            const uint32_t f = elem(i);
             ulonglong2 v = make_ulonglong2(0, 0);
-            uint64_t* src;
-            if (where(f, src))
-                v = *reinterpret_cast<const ulonglong2*>(src);
+            uint64_t off;
+            if (where(elem(i), off))
+                v = *reinterpret_cast<const ulonglong2*>(p.data + off);
             x[2 * i] = v.x;
             x[2 * i + 1] = v.y;
         }
         if (p.flags & PASS_CONDITION_INPUT)
             condition_all<A, REGS>(x, c);
+        if (p.flags & PASS_POINTWISE) {
+            // product of two forward transforms, element by element, ahead of the backward stages
+#pragma unroll
+            for (int i = 0; i < REGS / 2; i++) {
+                ulonglong2 v = make_ulonglong2(0, 0);
+                uint64_t off;
+                if (where(elem(i), off))
+                    v = *reinterpret_cast<const ulonglong2*>(p.data2 + off);
+                x[2 * i] = A::pointwise(x[2 * i], v.x, c);
+                x[2 * i + 1] = A::pointwise(x[2 * i + 1], v.y, c);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < REGS / 2; i++) {
             const uint32_t f = elem(i);
@@ -441,12 +455,12 @@ __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<
         for (int i = 0; i < REGS / 2; i++) {
             const uint32_t f = elem(i);
             const uint32_t a0 = f + (f >> 4);
-            uint64_t* dst;
-            if (where(f, dst)) {
+            uint64_t off;
+            if (where(f, off)) {
                 ulonglong2 v;
                 v.x = lds[a0];
                 v.y = lds[a0 + 1];
-                *reinterpret_cast<ulonglong2*>(dst) = v;
+                *reinterpret_cast<ulonglong2*>(p.data + off) = v;
             }
         }
     }

@@ -50,6 +50,10 @@ struct nttx_plan {
     nttx::MontCtx mctx{};
     nttx::Shoup61Ctx sctx{};
     nttx::GoldilocksCtx gctx{};
+    // same with n^-1 replaced by n^-1 * 2^64: the backward transform of a pointwise product,
+    // which the Montgomery-kind kernels form as a * b * 2^-64 (nttx_negacyclic_mul_*)
+    nttx::MontCtx mctx_mul{};
+    nttx::Shoup61Ctx sctx_mul{};
     std::vector<uint64_t> h_fwd, h_inv;       // tables as the caller passed them
     std::vector<nttx::TwPair> h_fwd2, h_inv2; // SHOUP61: plain twiddle + quotient
     std::vector<int> devices;
@@ -144,8 +148,9 @@ int device_slot(const nttx_plan* plan, int device)
 }
 
 // Launches pass `d` with parameters `p` (data, geometry and flags already set) over `tiles` tiles.
+// `product`: the backward transform of a pointwise product (contexts with n^-1 * 2^64).
 int launch_pass(const nttx_plan* plan, int slot, const PassDesc& d, PassParams p, uint64_t tiles, bool fwd,
-                hipStream_t stream)
+                hipStream_t stream, bool product = false)
 {
     if (tiles == 0 || tiles > 0x7fffffffull)
         return fail(NTTX_EINVAL, "element count is out of range for one launch");
@@ -168,9 +173,9 @@ int launch_pass(const nttx_plan* plan, int slot, const PassDesc& d, PassParams p
     hipError_t e;
     switch (plan->policy) {
     case nttx_plan::GOLDILOCKS: e = launch_dir<Goldilocks>(fwd, d, p, plan->gctx, (unsigned)tiles, stream); break;
-    case nttx_plan::MONT_WIDE: e = launch_dir<Mont<true>>(fwd, d, p, plan->mctx, (unsigned)tiles, stream); break;
-    case nttx_plan::MONT: e = launch_dir<Mont<false>>(fwd, d, p, plan->mctx, (unsigned)tiles, stream); break;
-    default: e = launch_dir<Shoup61>(fwd, d, p, plan->sctx, (unsigned)tiles, stream); break;
+    case nttx_plan::MONT_WIDE: e = launch_dir<Mont<true>>(fwd, d, p, product ? plan->mctx_mul : plan->mctx, (unsigned)tiles, stream); break;
+    case nttx_plan::MONT: e = launch_dir<Mont<false>>(fwd, d, p, product ? plan->mctx_mul : plan->mctx, (unsigned)tiles, stream); break;
+    default: e = launch_dir<Shoup61>(fwd, d, p, product ? plan->sctx_mul : plan->sctx, (unsigned)tiles, stream); break;
     }
     if (e != hipSuccess)
         return fail(NTTX_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -196,7 +201,7 @@ uint32_t pass_flags(const PassDesc& d, size_t fi, size_t np, bool fwd)
 // of 16 consecutive transforms, so a workgroup shares its twiddles) for the largest multiple of 16
 // transforms, and on plain contiguous tiles for the rest of the batch.
 int enqueue_passes(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream,
-                   int only_pass)
+                   int only_pass, const uint64_t* mul_with = nullptr)
 {
     static const bool no_xb = std::getenv("NTTX_NO_CROSS_BATCH") != nullptr;
     const size_t np = plan->passes.size();
@@ -220,7 +225,11 @@ int enqueue_passes(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch
             p.logB = plan->logn - d.s0;
             p.s0 = d.s0;
             p.flags = pass_flags(d, fi, np, fwd) | (part == 0 ? (uint32_t)PASS_CROSS_BATCH : 0u);
-            int rc = launch_pass(plan, slot, d, p, (total + TILE - 1) / TILE, fwd, stream);
+            if (mul_with && i == 0) { // the first backward pass multiplies by the other transform first
+                p.data2 = mul_with + ((uint64_t)first << plan->logn);
+                p.flags |= PASS_POINTWISE;
+            }
+            int rc = launch_pass(plan, slot, d, p, (total + TILE - 1) / TILE, fwd, stream, mul_with != nullptr);
             if (rc != NTTX_OK)
                 return rc;
         }
@@ -439,7 +448,7 @@ size_t chunk_bytes()
 
 // Enqueues one transform of `batch` vectors at dptr on the current device.
 int enqueue(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream,
-            int only_pass = -1)
+            int only_pass = -1, const uint64_t* mul_with = nullptr)
 {
     if (batch == 0)
         return NTTX_OK;
@@ -455,17 +464,32 @@ int enqueue(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool 
     }
     for (size_t first = 0; first < batch; first += per) {
         const size_t count = std::min(per, batch - first);
-        int rc = enqueue_passes(plan, slot, dptr + ((uint64_t)first << plan->logn), count, fwd, stream, only_pass);
+        int rc = enqueue_passes(plan, slot, dptr + ((uint64_t)first << plan->logn), count, fwd, stream, only_pass,
+                                mul_with ? mul_with + ((uint64_t)first << plan->logn) : nullptr);
         if (rc != NTTX_OK)
             return rc;
     }
     return NTTX_OK;
 }
 
+// a <- a * b in Z_q[X]/(X^n + 1) for `batch` pairs: forward(a), forward(b), then the backward
+// transform of a whose first pass multiplies by b element by element.  b == a squares (each tile
+// of the first backward pass is read completely before it is written).
+int enqueue_product(const nttx_plan* plan, int slot, uint64_t* a, uint64_t* b, size_t batch, hipStream_t stream)
+{
+    int rc = enqueue(plan, slot, a, batch, true, stream);
+    if (rc == NTTX_OK && b != a)
+        rc = enqueue(plan, slot, b, batch, true, stream);
+    if (rc == NTTX_OK)
+        rc = enqueue(plan, slot, a, batch, false, stream, -1, b);
+    return rc;
+}
+
 // Staging buffers up to this size stay allocated between host-slice calls.
 constexpr size_t HOST_SLOT_KEEP_BYTES = 256ull << 20;
 
-int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd)
+// `other` != NULL: negacyclic product data <- data * other instead of a transform (fwd ignored).
+int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd, const uint64_t* other = nullptr)
 {
     if (!plan)
         return fail(NTTX_EINVAL, "plan is NULL");
@@ -494,7 +518,8 @@ int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd)
             if (w.first >= batch)
                 break;
             w.count = std::min(per, batch - w.first);
-            const size_t bytes = (w.count << plan->logn) * sizeof(uint64_t);
+            const size_t vec_bytes = (w.count << plan->logn) * sizeof(uint64_t);
+            const size_t bytes = other ? 2 * vec_bytes : vec_bytes;
             HIP_TRY(hipSetDevice(plan->devices[i]));
             w.slot = plan->host_slots[i].get();
             w.guard = std::unique_lock<std::mutex>(w.slot->lock);
@@ -515,11 +540,18 @@ int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd)
                 w.own = true;
             }
             hipStream_t st = w.slot->stream;
-            HIP_TRY(hipMemcpyAsync(w.d, data + (w.first << plan->logn), bytes, hipMemcpyHostToDevice, st));
-            int r = enqueue(plan, (int)i, w.d, w.count, fwd, st);
+            HIP_TRY(hipMemcpyAsync(w.d, data + (w.first << plan->logn), vec_bytes, hipMemcpyHostToDevice, st));
+            int r;
+            if (other) {
+                uint64_t* d2 = w.d + (w.count << plan->logn);
+                HIP_TRY(hipMemcpyAsync(d2, other + (w.first << plan->logn), vec_bytes, hipMemcpyHostToDevice, st));
+                r = enqueue_product(plan, (int)i, w.d, d2, w.count, st);
+            } else {
+                r = enqueue(plan, (int)i, w.d, w.count, fwd, st);
+            }
             if (r != NTTX_OK)
                 return r;
-            HIP_TRY(hipMemcpyAsync(data + (w.first << plan->logn), w.d, bytes, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(data + (w.first << plan->logn), w.d, vec_bytes, hipMemcpyDeviceToHost, st));
         }
         for (size_t i = 0; i < ndev; i++) {
             if (!work[i].slot)
@@ -669,7 +701,10 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
         plan->policy = nttx_plan::SHOUP61; // 8q <= 2^64: lazy butterflies
     else
         plan->policy = (q >> 63) ? nttx_plan::MONT_WIDE : nttx_plan::MONT;
-    plan->mctx = nttx::MontCtx{q, k, (uint64_t)((((u128)1) << 64) % q), n_inv};
+    const uint64_t r_mod_q = (uint64_t)((((u128)1) << 64) % q);
+    plan->mctx = nttx::MontCtx{q, k, r_mod_q, n_inv};
+    plan->mctx_mul = plan->mctx;
+    plan->mctx_mul.n_inv_m = (uint64_t)(((u128)n_inv * r_mod_q) % q); // n^-1 * 2^128: REDC leaves n^-1 * 2^64
     plan->gctx = nttx::GoldilocksCtx{n_inv};
     try {
         plan->h_fwd.assign(psi_bo, psi_bo + n);
@@ -687,7 +722,10 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
             }
             const uint64_t n_inv_plain = mt.reduce((u128)n_inv);
             const uint64_t s1 = (uint64_t)(((u128)plan->h_inv2[1].w * n_inv_plain) % q);
-            plan->sctx = nttx::Shoup61Ctx{q, 2 * q, 4 * q, 0 - q, pair_of(1 % q), pair_of(n_inv_plain), pair_of(s1)};
+            plan->sctx = nttx::Shoup61Ctx{q, 2 * q, 4 * q, 0 - q, pair_of(1 % q), pair_of(n_inv_plain), pair_of(s1), k};
+            plan->sctx_mul = plan->sctx;
+            plan->sctx_mul.scale = pair_of((uint64_t)(((u128)n_inv_plain * r_mod_q) % q));
+            plan->sctx_mul.scale1 = pair_of((uint64_t)(((u128)s1 * r_mod_q) % q));
         }
     } catch (const std::bad_alloc&) {
         delete plan;
@@ -799,6 +837,41 @@ int nttx_forward_device(const nttx_plan* plan, int device, void* dptr, size_t ba
 int nttx_backward_device(const nttx_plan* plan, int device, void* dptr, size_t batch, void* hip_stream)
 {
     return run_device(plan, device, dptr, batch, hip_stream, false);
+}
+
+int nttx_negacyclic_mul_host(const nttx_plan* plan, uint64_t* a, const uint64_t* b, size_t batch)
+{
+    if (batch != 0 && !b)
+        return fail(NTTX_EINVAL, "second operand is NULL");
+    return run_host(plan, a, batch, true, batch ? b : nullptr);
+}
+
+int nttx_negacyclic_mul_device(const nttx_plan* plan, int device, void* a, void* b, size_t batch, void* hip_stream)
+{
+    if (!plan)
+        return fail(NTTX_EINVAL, "plan is NULL");
+    const int slot = device_slot(plan, device);
+    if (slot < 0)
+        return fail(NTTX_ENODEV, "device is not one of the plan's devices");
+    if (batch == 0)
+        return NTTX_OK;
+    if (!a || !b || ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15))
+        return fail(NTTX_EINVAL, "device pointers must be non-NULL and 16-byte aligned");
+    const uint64_t total = (uint64_t)batch << plan->logn;
+    if ((total >> plan->logn) != batch)
+        return fail(NTTX_EINVAL, "batch * n is too large");
+    uint64_t* pa = static_cast<uint64_t*>(a);
+    uint64_t* pb = static_cast<uint64_t*>(b);
+    if (pa != pb && pa < pb + total && pb < pa + total)
+        return fail(NTTX_EINVAL, "operands overlap (pass the same pointer twice to square)");
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != device)
+        HIP_TRY(hipSetDevice(device));
+    int rc = enqueue_product(plan, slot, pa, pb, batch, static_cast<hipStream_t>(hip_stream));
+    if (cur != device && cur >= 0)
+        (void)hipSetDevice(cur);
+    return rc;
 }
 
 int nttx_pass_count(const nttx_plan* plan) { return plan ? (int)plan->passes.size() : 0; }

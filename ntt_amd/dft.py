@@ -129,6 +129,28 @@ class _PlanTable(DFT):
     def backward_inplace_batch(self, x, batch):
         self._run_batch(x, batch, False)
 
+    # a <- a * b in Z_q[X]/(X^n + 1) for every pair of polynomials in the two batches; the composition
+    # forward(a), forward(b), coefficient-wise product, backward(a), fused (include/nttx.h)
+    def negacyclic_mul_inplace(self, a, b):
+        if isinstance(a, np.ndarray):
+            for x in (a, b):
+                if not isinstance(x, np.ndarray) or x.dtype != self._np_dtype or not x.flags.c_contiguous:
+                    raise TypeError("expected C-contiguous %s arrays" % np.dtype(self._np_dtype).name)
+            if not a.flags.writeable or a.size != b.size or a.size % self._n != 0:
+                raise Panic("operands must hold the same whole number of polynomials of n = %d" % self._n)
+            _check(lib.nttx_negacyclic_mul_host(self._plan, a.ctypes.data, b.ctypes.data, a.size // self._n))
+            return
+        import torch
+
+        for x in (a, b):
+            if not isinstance(x, torch.Tensor) or not x.is_cuda or not x.is_contiguous() or x.element_size() != 8:
+                raise TypeError("expected contiguous 64-bit integer tensors on a GPU")
+        if a.device != b.device or a.numel() != b.numel() or a.numel() % self._n != 0:
+            raise Panic("operands must hold the same whole number of polynomials of n = %d" % self._n)
+        stream = torch.cuda.current_stream(a.device).cuda_stream
+        _check(lib.nttx_negacyclic_mul_device(self._plan, a.device.index, a.data_ptr(), b.data_ptr(),
+                                              a.numel() // self._n, stream))
+
     # ONE transform split over several shards (a vector too large for one GPU); same result as
     # forward_inplace / backward_inplace on the whole slice.  n_shards = 0: one per plan device.
     def forward_inplace_distributed(self, x, n_shards=0):

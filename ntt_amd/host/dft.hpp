@@ -89,6 +89,15 @@ inline void run_distributed(const nttx_plan* plan, uint64_t n, void* x, size_t l
                   : nttx_backward_distributed(plan, static_cast<uint64_t*>(x), n_shards));
 }
 
+// a <- a * b in Z_q[X]/(X^n + 1): forward(a), forward(b), coefficient-wise product, backward(a),
+// fused on the device.  No counterpart in the reference (it is what its callers compose).
+inline void run_product(const nttx_plan* plan, uint64_t n, void* a, size_t len_a, const void* b, size_t len_b)
+{
+    if (len_a != n || len_b != n)
+        throw Panic("slice length does not match the table size");
+    check(nttx_negacyclic_mul_host(plan, static_cast<uint64_t*>(a), static_cast<const uint64_t*>(b), 1));
+}
+
 } // namespace detail
 
 template <class O>
@@ -151,6 +160,11 @@ class Table<uint64_t> : public DFT<uint64_t> {
     void backward_inplace_distributed(uint64_t* a, size_t len, int n_shards = 0) const
     {
         detail::run_distributed(plan_.get(), n_, a, len, false, n_shards);
+    }
+
+    void negacyclic_mul_inplace(std::vector<uint64_t>& a, const std::vector<uint64_t>& b) const
+    {
+        detail::run_product(plan_.get(), n_, a.data(), a.size(), b.data(), b.size());
     }
 
     const nttx_plan* plan() const { return plan_.get(); }
@@ -219,6 +233,11 @@ class TableAVX2 : public DFT<int64_t> {
     void backward_inplace_distributed(int64_t* a, size_t len, int n_shards = 0) const
     {
         detail::run_distributed(plan_.get(), n_, a, len, false, n_shards);
+    }
+
+    void negacyclic_mul_inplace(std::vector<int64_t>& a, const std::vector<int64_t>& b) const
+    {
+        detail::run_product(plan_.get(), n_, a.data(), a.size(), b.data(), b.size());
     }
 
     const nttx_plan* plan() const { return plan_.get(); }
@@ -290,6 +309,11 @@ class TableGoldilock<uint64_t> : public DFT<uint64_t> {
     void backward_inplace_distributed(uint64_t* a, size_t len, int n_shards = 0) const
     {
         detail::run_distributed(plan_.get(), n_, a, len, false, n_shards);
+    }
+
+    void negacyclic_mul_inplace(std::vector<uint64_t>& a, const std::vector<uint64_t>& b) const
+    {
+        detail::run_product(plan_.get(), n_, a.data(), a.size(), b.data(), b.size());
     }
 
     const nttx_plan* plan() const { return plan_.get(); }

@@ -26,6 +26,8 @@ extern "C" {
     pub fn nttx_backward_host(plan: *const NttxPlan, data: *mut u64, batch: usize) -> c_int;
     pub fn nttx_forward_device(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, stream: *mut c_void) -> c_int;
     pub fn nttx_backward_device(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, stream: *mut c_void) -> c_int;
+    pub fn nttx_negacyclic_mul_host(plan: *const NttxPlan, a: *mut u64, b: *const u64, batch: usize) -> c_int;
+    pub fn nttx_negacyclic_mul_device(plan: *const NttxPlan, device: c_int, a: *mut c_void, b: *mut c_void, batch: usize, stream: *mut c_void) -> c_int;
     pub fn nttx_forward_distributed(plan: *const NttxPlan, host_data: *mut u64, n_shards: c_int) -> c_int;
     pub fn nttx_backward_distributed(plan: *const NttxPlan, host_data: *mut u64, n_shards: c_int) -> c_int;
     pub fn nttx_shard_geometry(plan: *const NttxPlan, n_shards: c_int, local_elems: *mut u64, rows: *mut u64,

@@ -26,7 +26,7 @@ static uint64_t mulmod(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)((
 static Shoup61Ctx make_shoup_ctx(uint64_t q, uint64_t n_inv_plain, uint64_t s1_plain)
 {
     auto pair_of = [&](uint64_t w) { return TwPair{w, (uint64_t)(((u128)w << 64) / q)}; };
-    return Shoup61Ctx{q, 2 * q, 4 * q, 0 - q, pair_of(1), pair_of(n_inv_plain), pair_of(s1_plain)};
+    return Shoup61Ctx{q, 2 * q, 4 * q, 0 - q, pair_of(1), pair_of(n_inv_plain), pair_of(s1_plain), 0};
 }
 
 static void shoup_mul_bounds(uint64_t q)

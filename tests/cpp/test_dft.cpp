@@ -161,9 +161,39 @@ static void split_equals_unsplit()
     CHECK(threw);
 }
 
+// X^(n-1) * X = -1 and (1 + X)^2 = 1 + 2X + X^2 in Z_q[X]/(X^n + 1), all three tables.
+static void negacyclic_product()
+{
+    auto table = Table<uint64_t>::new_();
+    const size_t n = 1 << 16;
+    std::vector<uint64_t> a(n, 0), b(n, 0);
+    a[n - 1] = 1;
+    b[1] = 1;
+    table.negacyclic_mul_inplace(a, b);
+    CHECK(a[0] == table.q - 1);
+    for (size_t i = 1; i < n; i++)
+        if (a[i] != 0) { CHECK(a[i] == 0); break; }
+    CHECK(b[1] == 1 && b[0] == 0); // the host entry point leaves b alone
+
+    auto gl = TableGoldilock<uint64_t>::new_();
+    std::vector<uint64_t> c(n, 0);
+    c[0] = c[1] = 1;
+    auto d = c;
+    gl.negacyclic_mul_inplace(c, d);
+    CHECK(c[0] == 1 && c[1] == 2 && c[2] == 1 && c[3] == 0);
+
+    auto avx = TableAVX2::new_();
+    std::vector<int64_t> e(n, 0), f(n, 0);
+    e[n - 1] = 3;
+    f[2] = 5;
+    avx.negacyclic_mul_inplace(e, f);
+    CHECK(e[1] == avx.q - 15 && e[0] == 0);
+}
+
 int main()
 {
     utils_tests();
+    negacyclic_product();
     split_equals_unsplit();
     base_version();
     avx_correctness();

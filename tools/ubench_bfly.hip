@@ -63,7 +63,7 @@ int main()
     GoldilocksCtx gc{0xfffeffff00010001ull};
     run<Mont<false>, true>("mont strict fwd", mc, q);
     run<Mont<false>, false>("mont strict bwd", mc, q);
-    Shoup61Ctx sc{q, 2 * q, 4 * q, 0 - q, {1, (uint64_t)((((unsigned __int128)1) << 64) / q)}, {5, 40}, {7, 56}};
+    Shoup61Ctx sc{q, 2 * q, 4 * q, 0 - q, {1, (uint64_t)((((unsigned __int128)1) << 64) / q)}, {5, 40}, {7, 56}, 0};
     run<Shoup61, true>("shoup61 lazy fwd", sc, q);
     run<Shoup61, false>("shoup61 lazy bwd", sc, q);
     run<Mont<true>, true>("mont wide fwd", mc, q);
