@@ -426,3 +426,33 @@ def test_one_plan_many_host_threads(amd):
     assert not errors, errors
     for i in range(len(inputs)):
         assert np.array_equal(got[i], want[i]), i
+
+
+def test_device_entry_points_under_graph_capture(amd):
+    """The device entry points only enqueue kernels on the given stream (no allocation, no
+    synchronisation), so a transform pair can be captured into a HIP graph and replayed."""
+    import torch
+    n, batch = 1 << 16, 32
+    gpu, ref = amd.Table.new(), orc.Table.new()
+    a = orc.splitmix_residues(Q61, n * batch, 800)
+    d = torch.from_numpy(a.view(np.int64).copy()).cuda()
+    fwd_out = torch.empty_like(d)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        gpu.forward_inplace(d)      # warm-up outside capture
+        gpu.backward_inplace(d)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        gpu.forward_inplace(d)
+        fwd_out.copy_(d)
+        gpu.backward_inplace(d)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    want = a[:n].copy()
+    ref.forward_inplace(want)
+    assert np.array_equal(fwd_out[:n].cpu().numpy().view(np.uint64), want)
+    assert np.array_equal(d.cpu().numpy().view(np.uint64), a)
