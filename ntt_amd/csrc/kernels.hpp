@@ -51,6 +51,7 @@ struct PassParams {
     uint32_t logB;            // log2 of the block size n >> s0
     uint32_t s0;              // stages that precede this pass in forward order
     uint32_t flags;
+    uint32_t xcd_group;       // 0: tile = workgroup id.  G > 0: runs of G consecutive tiles per XCD (see pass_kernel)
 };
 
 // Twiddles of K stages for twiddle base P: entry (1 << (u-1)) + b of `w` is
@@ -636,7 +637,16 @@ __global__ __launch_bounds__(THREADS, 4) void pass_kernel(PassParams p, typename
 {
     constexpr int K = K1 + K2;
     __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
-    const TileGeom<K, XB> g(p, blockIdx.x);
+    // Workgroups are handed to the 8 XCDs round-robin (id % 8).  With xcd_group = G the tiles are
+    // dealt so that each XCD works on runs of G consecutive tiles: workgroup id -> run
+    // (id / 8G) * 8 + id % 8, position (id / 8) % G inside it.  The host only sets G when the
+    // grid is a multiple of 8G.
+    uint64_t tile = blockIdx.x;
+    if (p.xcd_group) {
+        const uint32_t G = p.xcd_group;
+        tile = ((uint64_t)(blockIdx.x / (8 * G)) * 8 + blockIdx.x % 8) * G + (blockIdx.x / 8) % G;
+    }
+    const TileGeom<K, XB> g(p, tile);
 
     if constexpr (K1 == 4 && K2 == 4) {
         __shared__ __attribute__((aligned(16))) typename A::TwElem ldstw[LDSTW_ELEMS];

@@ -109,6 +109,7 @@ std::vector<PassDesc> make_passes(uint32_t logn)
 template <class A, bool FWD, bool CONTIG, int K1, int K2, bool XB = false>
 hipError_t launch_one(const PassParams& p, const typename A::Ctx& c, unsigned grid, hipStream_t s)
 {
+    (void)hipGetLastError(); // drop any error an earlier, unrelated call left behind on this thread
     hipLaunchKernelGGL((pass_kernel<A, FWD, CONTIG, K1, K2, XB>), dim3(grid), dim3(THREADS), 0, s, p, c);
     return hipGetLastError();
 }
@@ -164,6 +165,21 @@ int launch_pass(const nttx_plan* plan, int slot, const PassDesc& d, PassParams p
                                                                           : (uint32_t)PASS_DEBUG_NO_MATH;
     }();
     p.flags |= no_math;
+    // STRIDED passes: all tiles of a block (they share its rows, 128 bytes each) go to one XCD.
+    // Measured on the headline workload: 0.80 ms instead of 0.83 ms for the memory-bound forward
+    // pass; no gain for CONTIG tiles.  NTTX_XCD_GROUP=<G> forces runs of G tiles on every pass
+    // (0 = plain order) for experiments.
+    static const long xcd_group = [] {
+        const char* e = std::getenv("NTTX_XCD_GROUP");
+        return e ? std::atol(e) : -1L;
+    }();
+    uint64_t group = 0;
+    if (xcd_group >= 0)
+        group = (uint64_t)xcd_group;
+    else if (!d.contig && p.logB >= (uint32_t)TILE_LOG)
+        group = 1ull << (p.logB - TILE_LOG);
+    if (group > 0 && group <= (1u << 20) && tiles % (8 * group) == 0)
+        p.xcd_group = (uint32_t)group;
     static const bool no_finish = std::getenv("NTTX_DEBUG_NO_FINISH") != nullptr;
     if (no_finish)
         p.flags &= ~PASS_FINISH;
@@ -602,17 +618,19 @@ int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return fail(NTTX_ENODEV, "no HIP device available");
+    std::vector<int> devs;
     if (devices == nullptr || n_devices <= 0)
-        plan->devices = {0};
+        devs = {0};
     else
-        plan->devices.assign(devices, devices + n_devices);
-    for (size_t i = 0; i < plan->devices.size(); i++) {
-        if (plan->devices[i] < 0 || plan->devices[i] >= count)
+        devs.assign(devices, devices + n_devices);
+    for (size_t i = 0; i < devs.size(); i++) {
+        if (devs[i] < 0 || devs[i] >= count)
             return fail(NTTX_ENODEV, "device index out of range");
         for (size_t j = 0; j < i; j++)
-            if (plan->devices[j] == plan->devices[i])
+            if (devs[j] == devs[i])
                 return fail(NTTX_EINVAL, "device listed twice");
     }
+    plan->devices = devs; // only validated indices reach the plan (its destructor visits them)
     int prev = 0;
     (void)hipGetDevice(&prev);
     const bool pairs = plan->policy == nttx_plan::SHOUP61;
