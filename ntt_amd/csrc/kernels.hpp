@@ -36,6 +36,7 @@ enum : uint32_t {
     PASS_DEBUG_NO_TW = 16u,    // profiling aid (NTTX_DEBUG_NO_TW=1, with NO_MATH): skip the twiddle loads too
     PASS_DEBUG_NO_MATH_A = 32u, // profiling aids (NTTX_DEBUG_NO_MATH=A / B): skip one register round of the 8-stage pass
     PASS_DEBUG_NO_MATH_B = 64u,
+    PASS_OFFSET32 = 512u,      // every element of a tile lies within 2^31 bytes of the tile's first: buffer addressing
     PASS_POINTWISE = 256u,     // first pass of a backward transform: multiply by the vector at data2 first
     PASS_CROSS_BATCH = 128u    // CONTIG 8-stage pass: a tile is the same 256-element block of 16 consecutive transforms
 };
@@ -249,12 +250,66 @@ struct TileGeom {
         return (block_of(sigma) << logB) + ((uint64_t)r << logT) + column_of(sigma);
     }
     __device__ __forceinline__ bool valid(uint32_t sigma) const { return block_of(sigma) < nblocks_total; }
+    // gidx(sigma, r) = uniform_index() + lane_index(sigma, r): a wave-uniform part (scalar
+    // registers) and a per-lane part that fits 32 bits when the host sets PASS_OFFSET32.
+    __device__ __forceinline__ uint64_t uniform_index() const
+    {
+        if (XB)
+            return ((((tile >> s0) << 4) << s0) + (tile & ((1ull << s0) - 1))) << logB;
+        return ((((tile >> logtpb) << lognblk)) << logB) + ((tile & ((1ull << logtpb) - 1)) << logCw);
+    }
+    __device__ __forceinline__ uint64_t lane_index(uint32_t sigma, uint32_t r) const
+    {
+        if (XB)
+            return ((uint64_t)sigma << (s0 + logB)) + ((uint64_t)r << logT);
+        return ((uint64_t)(sigma >> logCw) << logB) + ((uint64_t)r << logT) + (sigma & ((1u << logCw) - 1));
+    }
     // twiddle base of the block: 2^s0 + (block index inside its transform)
     __device__ __forceinline__ uint64_t twiddle_base(uint32_t sigma) const
     {
         return (1ull << s0) + ((block_base + block_of(sigma)) & ((1ull << s0) - 1));
     }
 };
+
+// Buffer addressing (scalar resource + 32-bit lane offset + scalar offset): the address of an
+// element costs no vector arithmetic.  The resource starts at a tile's first element and spans
+// 4 GiB, so the range check never fires; callers keep every offset inside the allocation.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_resource(const uint64_t* first)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(first), 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ uint64_t buffer_load64(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes)
+{
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, uniform_bytes, 0);
+    return pack64(v.x, v.y);
+}
+__device__ __forceinline__ ulonglong2 buffer_load128(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes)
+{
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, uniform_bytes, 0);
+    return make_ulonglong2(pack64(v.x, v.y), pack64(v.z, v.w));
+}
+__device__ __forceinline__ void buffer_store128(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes,
+                                                ulonglong2 x)
+{
+    const u32x4_t v = {lo32(x.x), hi32(x.x), lo32(x.y), hi32(x.y)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, lane_bytes, uniform_bytes, 0);
+}
+__device__ __forceinline__ void buffer_store64(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes,
+                                               uint64_t x)
+{
+    const u32x2_t v = {lo32(x), hi32(x)};
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, lane_bytes, uniform_bytes, 0);
+}
+
+// Tests a pass flag through an opaque scalar copy: the compiler then cannot tell that two tests
+// of the same flag agree, and does not clone everything between them for each outcome.
+__device__ __forceinline__ bool flag_set(uint32_t flags, uint32_t bit)
+{
+    asm volatile("" : "+s"(flags));
+    return flags & bit;
+}
 
 // One register round of a pass for one group of 2^KR registers.  ROUND_A covers the K1 stages
 // with the larger strides (elements rlow + (i << K2)), round B the K2 stages with the smaller
@@ -291,19 +346,31 @@ struct Round {
         P = ok ? (ROUND_A ? base : ((base << K1) + rpart)) : 1;
     }
 
+    // A sub-transform past the end of the buffer (ragged last tile) reads the tile's first
+    // block or transform instead -- always inside the buffer -- and stores nothing.
+    __device__ __forceinline__ uint32_t safe_sigma(const Geom& g) const
+    {
+        if (ok)
+            return sigma;
+        return XB ? 0u : (sigma & ((1u << g.logCw) - 1));
+    }
     __device__ __forceinline__ void load_global(uint64_t (&x)[M], const PassParams& p, const Geom& g,
                                                 const typename A::Ctx& c) const
     {
-        if (ok) {
-            const uint64_t* src = p.data + g.gidx(sigma, r0);
+        const uint32_t ss = safe_sigma(g);
+        if (flag_set(p.flags, PASS_OFFSET32)) {
+            const __amdgpu_buffer_rsrc_t res = tile_resource(p.data + g.uniform_index());
+            const uint32_t lane = (uint32_t)g.lane_index(ss, r0) * 8u;
+            const uint32_t stepb = 8u << (g.logT + rstep_log);
+#pragma unroll
+            for (int i = 0; i < M; i++)
+                x[i] = buffer_load64(res, lane, i * stepb);
+        } else {
+            const uint64_t* src = p.data + g.uniform_index() + g.lane_index(ss, r0);
             const uint64_t step = 1ull << (g.logT + rstep_log);
 #pragma unroll
             for (int i = 0; i < M; i++)
                 x[i] = src[i * step];
-        } else {
-#pragma unroll
-            for (int i = 0; i < M; i++)
-                x[i] = 0;
         }
         if (p.flags & PASS_CONDITION_INPUT)
             condition_all<A, M>(x, c);
@@ -311,7 +378,16 @@ struct Round {
     __device__ __forceinline__ void store_global(const uint64_t (&x)[M], const PassParams& p,
                                                  const Geom& g) const
     {
-        if (ok) {
+        if (!ok)
+            return;
+        if (flag_set(p.flags, PASS_OFFSET32)) {
+            const __amdgpu_buffer_rsrc_t res = tile_resource(p.data + g.uniform_index());
+            const uint32_t lane = (uint32_t)g.lane_index(sigma, r0) * 8u;
+            const uint32_t stepb = 8u << (g.logT + rstep_log);
+#pragma unroll
+            for (int i = 0; i < M; i++)
+                buffer_store64(res, lane, i * stepb, x[i]);
+        } else {
             uint64_t* dst = p.data + g.gidx(sigma, r0);
             const uint64_t step = 1ull << (g.logT + rstep_log);
 #pragma unroll
@@ -419,14 +495,41 @@ __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<
         off = base + f;
         return base + f < total; // total is a multiple of 4 (n >= 4)
     };
+    // Buffer addressing: element f = uniform part (run or step) + lane part, both in bytes from
+    // the tile's first element.
+    const bool buffers = flag_set(p.flags, PASS_OFFSET32);
+    const uint64_t first = XB ? run0 : base;
+    auto split = [&](uint32_t f, uint32_t& uniform_bytes, uint32_t& lane_bytes) {
+        if (XB) {
+            const uint32_t sigma = __builtin_amdgcn_readfirstlane(f >> K);
+            uniform_bytes = sigma * (uint32_t)(run_stride * 8);
+            lane_bytes = (f & ((1u << K) - 1)) * 8;
+        } else {
+            const uint32_t lane_f = PER_WAVE ? 2 * (threadIdx.x & 63) : (K == 8 ? 2 * (threadIdx.x & 127) : 2 * threadIdx.x);
+            lane_bytes = lane_f * 8;
+            uniform_bytes = __builtin_amdgcn_readfirstlane(f - lane_f) * 8;
+        }
+    };
+    auto load_pair = [&](const uint64_t* from, int i) -> ulonglong2 {
+        ulonglong2 v = make_ulonglong2(0, 0);
+        uint64_t off;
+        const uint32_t f = elem(i);
+        if (where(f, off)) {
+            if (buffers) {
+                uint32_t ub, lb;
+                split(f, ub, lb);
+                v = buffer_load128(tile_resource(from + first), lb, ub);
+            } else {
+                v = *reinterpret_cast<const ulonglong2*>(from + off);
+            }
+        }
+        return v;
+    };
     if (TO_LDS) {
         uint64_t x[REGS];
 #pragma unroll
         for (int i = 0; i < REGS / 2; i++) {
-            ulonglong2 v = make_ulonglong2(0, 0);
-            uint64_t off;
-            if (where(elem(i), off))
-                v = *reinterpret_cast<const ulonglong2*>(p.data + off);
+            const ulonglong2 v = load_pair(p.data, i);
             x[2 * i] = v.x;
             x[2 * i + 1] = v.y;
         }
@@ -436,10 +539,7 @@ __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<
             // product of two forward transforms, element by element, ahead of the backward stages
 #pragma unroll
             for (int i = 0; i < REGS / 2; i++) {
-                ulonglong2 v = make_ulonglong2(0, 0);
-                uint64_t off;
-                if (where(elem(i), off))
-                    v = *reinterpret_cast<const ulonglong2*>(p.data2 + off);
+                const ulonglong2 v = load_pair(p.data2, i);
                 x[2 * i] = A::pointwise(x[2 * i], v.x, c);
                 x[2 * i + 1] = A::pointwise(x[2 * i + 1], v.y, c);
             }
@@ -461,7 +561,13 @@ __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<
                 ulonglong2 v;
                 v.x = lds[a0];
                 v.y = lds[a0 + 1];
-                *reinterpret_cast<ulonglong2*>(p.data + off) = v;
+                if (buffers) {
+                    uint32_t ub, lb;
+                    split(f, ub, lb);
+                    buffer_store128(tile_resource(p.data + first), lb, ub, v);
+                } else {
+                    *reinterpret_cast<ulonglong2*>(p.data + off) = v;
+                }
             }
         }
     }

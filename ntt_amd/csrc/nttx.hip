@@ -165,6 +165,11 @@ int launch_pass(const nttx_plan* plan, int slot, const PassDesc& d, PassParams p
                                                                           : (uint32_t)PASS_DEBUG_NO_MATH;
     }();
     p.flags |= no_math;
+    // Every element a workgroup touches lies within 2^31 bytes of its tile's first element when a
+    // block (or, for cross-batch tiles, 16 transforms) spans at most 2^28 elements.
+    static const bool no_buffer = std::getenv("NTTX_NO_BUFFER_ADDRESSING") != nullptr;
+    if (!no_buffer && ((p.flags & PASS_CROSS_BATCH) ? plan->logn + 4 <= 28 : p.logB <= 28))
+        p.flags |= PASS_OFFSET32;
     // STRIDED passes: all tiles of a block (they share its rows, 128 bytes each) go to one XCD.
     // Measured on the headline workload: 0.80 ms instead of 0.83 ms for the memory-bound forward
     // pass; no gain for CONTIG tiles.  NTTX_XCD_GROUP=<G> forces runs of G tiles on every pass
