@@ -459,72 +459,66 @@ __device__ __forceinline__ void wave_sync()
 // Copies a CONTIG tile between HBM and LDS, 16 bytes per lane.  XB: the tile is 16 runs of 256
 // elements (cross-batch tile) instead of one run of 4096.
 // PER_WAVE: every wave moves its own quarter of the tile (elements [1024 w, 1024 w + 1024)).
+//
+// Step i of a thread handles tile elements f, f + 1 with f = fu(i) + fl: fl depends on the lane
+// only and fu(i) is wave-uniform, so run numbers, bounds checks and the uniform part of every
+// address stay in scalar registers and the lane parts are computed once.
 template <class A, int K, bool TO_LDS, bool XB = false, bool PER_WAVE = false>
 __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<K, XB>& g, const typename A::Ctx& c,
                                             uint64_t* lds)
 {
-    const uint64_t total = p.nblocks_total << p.logB;
-    const uint64_t base = g.tile << TILE_LOG;
-    // cross-batch tile: run sigma (256 elements of transform 16 tau + sigma) starts n elements
-    // after run sigma - 1; everything but the lane offset is wave-uniform
+    static_assert(!XB || K == 8, "cross-batch tiles have 256-element runs");
+    uint32_t fl, group = 0;
+    if (PER_WAVE) {
+        group = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        fl = 2 * (threadIdx.x & 63);
+    } else if (K == 8) {
+        group = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
+        fl = 2 * (threadIdx.x & 127);
+    } else {
+        fl = 2 * threadIdx.x;
+    }
+    auto fu = [&](int i) -> uint32_t {
+        if (PER_WAVE)
+            return group * (TILE / 4) + i * 128;
+        if (K == 8)
+            return (2 * i + group) * 256;
+        return 2 * i * THREADS;
+    };
+    // first element of the tile in the buffer, and what is left of the buffer from there
     const uint64_t tau16 = (g.tile >> g.s0) << 4;
-    const uint64_t run0 = (((tau16 << g.s0) + (g.tile & ((1ull << g.s0) - 1))) << K);
-    const uint64_t run_stride = 1ull << (g.s0 + K);
-    const uint64_t runs_valid = (p.nblocks_total >> g.s0) - tau16; // transforms left from the tile's first
-    // element handled in step i.  With K = 8 its run f >> 8 is made explicitly wave-uniform so
-    // that run addresses and bounds checks stay in scalar registers.
-    auto elem = [](int i) -> uint32_t {
-        if (PER_WAVE) {
-            const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-            return wave * (TILE / 4) + i * 128 + 2 * (threadIdx.x & 63);
-        }
-        if (K == 8) {
-            const uint32_t half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
-            return (2 * i + half) * 256 + 2 * (threadIdx.x & 127);
-        }
-        return 2 * (i * THREADS + threadIdx.x);
+    const uint64_t first = XB ? (((tau16 << g.s0) + (g.tile & ((1ull << g.s0) - 1))) << K) : (g.tile << TILE_LOG);
+    const uint64_t run_stride = 1ull << (g.s0 + K); // XB: run sigma starts n elements after run sigma - 1
+    uint32_t left;                                   // XB: runs (transforms) present; else: elements present
+    if (XB) {
+        const uint64_t runs = (p.nblocks_total >> g.s0) - tau16;
+        left = runs < 16 ? (uint32_t)runs : 16u;
+    } else {
+        const uint64_t rest = (p.nblocks_total << p.logB) - first;
+        left = rest < TILE ? (uint32_t)rest : (uint32_t)TILE;
+    }
+    // uniform element offset of step i from `first`, and whether lane fl takes part (n >= 4 makes
+    // the element count a multiple of 4, and f is even: pairs are present or absent together)
+    auto uniform_elems = [&](int i) -> uint64_t {
+        const uint32_t u = fu(i);
+        return XB ? (u >> K) * run_stride + (u & ((1u << K) - 1)) : (uint64_t)u;
     };
-    // element f of the tile: its offset in the buffer and whether it exists (f is even; pairs
-    // never straddle runs)
-    auto where = [&](uint32_t f, uint64_t& off) -> bool {
-        if (XB) {
-            const uint32_t sigma = __builtin_amdgcn_readfirstlane(f >> K);
-            off = run0 + sigma * run_stride + (f & ((1u << K) - 1));
-            return sigma < runs_valid;
-        }
-        off = base + f;
-        return base + f < total; // total is a multiple of 4 (n >= 4)
-    };
-    // Buffer addressing: element f = uniform part (run or step) + lane part, both in bytes from
-    // the tile's first element.
+    auto present = [&](int i) -> bool { return XB ? (fu(i) >> K) < left : fu(i) + fl < left; };
     const bool buffers = flag_set(p.flags, PASS_OFFSET32);
-    const uint64_t first = XB ? run0 : base;
-    auto split = [&](uint32_t f, uint32_t& uniform_bytes, uint32_t& lane_bytes) {
-        if (XB) {
-            const uint32_t sigma = __builtin_amdgcn_readfirstlane(f >> K);
-            uniform_bytes = sigma * (uint32_t)(run_stride * 8);
-            lane_bytes = (f & ((1u << K) - 1)) * 8;
-        } else {
-            const uint32_t lane_f = PER_WAVE ? 2 * (threadIdx.x & 63) : (K == 8 ? 2 * (threadIdx.x & 127) : 2 * threadIdx.x);
-            lane_bytes = lane_f * 8;
-            uniform_bytes = __builtin_amdgcn_readfirstlane(f - lane_f) * 8;
-        }
-    };
     auto load_pair = [&](const uint64_t* from, int i) -> ulonglong2 {
         ulonglong2 v = make_ulonglong2(0, 0);
-        uint64_t off;
-        const uint32_t f = elem(i);
-        if (where(f, off)) {
-            if (buffers) {
-                uint32_t ub, lb;
-                split(f, ub, lb);
-                v = buffer_load128(tile_resource(from + first), lb, ub);
-            } else {
-                v = *reinterpret_cast<const ulonglong2*>(from + off);
-            }
+        if (present(i)) {
+            if (buffers)
+                v = buffer_load128(tile_resource(from + first), fl * 8, (uint32_t)uniform_elems(i) * 8);
+            else
+                v = *reinterpret_cast<const ulonglong2*>(from + first + uniform_elems(i) + fl);
         }
         return v;
     };
+    // LDS position of element f: f + (f >> 4) = [fu + (fu >> 4)] + [fl + (fl >> 4)] (fu is a multiple of 16)
+    uint64_t* const lane_lds = lds + (fl + (fl >> 4));
+    auto lds_of = [&](int i) -> uint64_t* { return lane_lds + (fu(i) + (fu(i) >> 4)); };
+
     if (TO_LDS) {
         uint64_t x[REGS];
 #pragma unroll
@@ -546,28 +540,22 @@ __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<
         }
 #pragma unroll
         for (int i = 0; i < REGS / 2; i++) {
-            const uint32_t f = elem(i);
-            const uint32_t a0 = f + (f >> 4); // f is even, so f and f+1 share a padding group
-            lds[a0] = x[2 * i];
-            lds[a0 + 1] = x[2 * i + 1];
+            uint64_t* const at = lds_of(i); // f is even, so f and f + 1 share a padding group
+            at[0] = x[2 * i];
+            at[1] = x[2 * i + 1];
         }
     } else {
 #pragma unroll
         for (int i = 0; i < REGS / 2; i++) {
-            const uint32_t f = elem(i);
-            const uint32_t a0 = f + (f >> 4);
-            uint64_t off;
-            if (where(f, off)) {
+            if (present(i)) {
+                const uint64_t* const at = lds_of(i);
                 ulonglong2 v;
-                v.x = lds[a0];
-                v.y = lds[a0 + 1];
-                if (buffers) {
-                    uint32_t ub, lb;
-                    split(f, ub, lb);
-                    buffer_store128(tile_resource(p.data + first), lb, ub, v);
-                } else {
-                    *reinterpret_cast<ulonglong2*>(p.data + off) = v;
-                }
+                v.x = at[0];
+                v.y = at[1];
+                if (buffers)
+                    buffer_store128(tile_resource(p.data + first), fl * 8, (uint32_t)uniform_elems(i) * 8, v);
+                else
+                    *reinterpret_cast<ulonglong2*>(p.data + first + uniform_elems(i) + fl) = v;
             }
         }
     }
