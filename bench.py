@@ -116,6 +116,8 @@ def main():
         table.forward_inplace(data)
         table.backward_inplace(data)
 
+    for _ in range(5):  # settle clocks and caches before the counted warm-up, whatever W is
+        step()
     for _ in range(args.warmup):
         step()
     barrier()
