@@ -687,4 +687,16 @@ struct Goldilocks {
     static NTTX_HD uint64_t pointwise(uint64_t a, uint64_t b, const Ctx&) { return mul_strict(a, b); }
 };
 
+// The Goldilocks prime behind the Montgomery-kind interface (Table::new_goldilock, ntt.rs:60-62):
+// Table<u64> reduces its input first (ntt.rs:125-127) and ends with canonical residues
+// (ntt.rs:173-175), whatever happens in between.  The Goldilocks butterflies are correct modulo q
+// on any u64, so they serve with a reduction of the input (x >= q -> x - q: 2q > 2^64) and of
+// the forward output (the one non-canonical value they can produce is q itself).  Twiddles and
+// n^-1 are taken out of Montgomery form when the plan is created.
+struct GoldilocksCanonical : Goldilocks {
+    static constexpr bool CONDITIONS_INPUT = true;
+    static NTTX_HD uint64_t condition_input(uint64_t x, const Ctx&) { return x >= Q ? x - Q : x; }
+    static NTTX_HD uint64_t finish(uint64_t x, const Ctx&) { return x == Q ? 0 : x; }
+};
+
 } // namespace nttx

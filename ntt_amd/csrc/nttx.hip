@@ -46,7 +46,7 @@ struct nttx_plan {
     uint64_t q = 0, k = 0, n = 0, n_inv = 0;
     uint32_t logn = 0;
     // arithmetic policy of the kernels (arith.hpp)
-    enum Policy { SHOUP61, MONT, MONT_WIDE, GOLDILOCKS } policy = MONT;
+    enum Policy { SHOUP61, MONT, MONT_WIDE, GOLDILOCKS, GOLDILOCKS_CANONICAL } policy = MONT;
     nttx::MontCtx mctx{};
     nttx::Shoup61Ctx sctx{};
     nttx::GoldilocksCtx gctx{};
@@ -56,6 +56,7 @@ struct nttx_plan {
     nttx::Shoup61Ctx sctx_mul{};
     std::vector<uint64_t> h_fwd, h_inv;       // tables as the caller passed them
     std::vector<nttx::TwPair> h_fwd2, h_inv2; // SHOUP61: plain twiddle + quotient
+    std::vector<uint64_t> h_fwd_plain, h_inv_plain; // GOLDILOCKS_CANONICAL: twiddles out of Montgomery form
     std::vector<int> devices;
     std::vector<void*> d_fwd, d_inv;           // per device: tables in the reference's index order
     std::vector<void*> d_fwd_perm, d_inv_perm; // per device: last four stages regrouped (permuted_index)
@@ -194,6 +195,9 @@ int launch_pass(const nttx_plan* plan, int slot, const PassDesc& d, PassParams p
     hipError_t e;
     switch (plan->policy) {
     case nttx_plan::GOLDILOCKS: e = launch_dir<Goldilocks>(fwd, d, p, plan->gctx, (unsigned)tiles, stream); break;
+    case nttx_plan::GOLDILOCKS_CANONICAL:
+        e = launch_dir<GoldilocksCanonical>(fwd, d, p, plan->gctx, (unsigned)tiles, stream);
+        break;
     case nttx_plan::MONT_WIDE: e = launch_dir<Mont<true>>(fwd, d, p, product ? plan->mctx_mul : plan->mctx, (unsigned)tiles, stream); break;
     case nttx_plan::MONT: e = launch_dir<Mont<false>>(fwd, d, p, product ? plan->mctx_mul : plan->mctx, (unsigned)tiles, stream); break;
     default: e = launch_dir<Shoup61>(fwd, d, p, product ? plan->sctx_mul : plan->sctx, (unsigned)tiles, stream); break;
@@ -641,8 +645,11 @@ int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
     const bool pairs = plan->policy == nttx_plan::SHOUP61;
     const size_t esz = pairs ? sizeof(nttx::TwPair) : sizeof(uint64_t);
     const size_t bytes = plan->n * esz;
-    const char* src_fwd = pairs ? (const char*)plan->h_fwd2.data() : (const char*)plan->h_fwd.data();
-    const char* src_inv = pairs ? (const char*)plan->h_inv2.data() : (const char*)plan->h_inv.data();
+    const bool plain = plan->policy == nttx_plan::GOLDILOCKS_CANONICAL;
+    const char* src_fwd = pairs ? (const char*)plan->h_fwd2.data()
+                                : plain ? (const char*)plan->h_fwd_plain.data() : (const char*)plan->h_fwd.data();
+    const char* src_inv = pairs ? (const char*)plan->h_inv2.data()
+                                : plain ? (const char*)plan->h_inv_plain.data() : (const char*)plan->h_inv.data();
     // regrouped copies for the pass that holds the last four stages
     std::vector<char> perm_fwd(bytes), perm_inv(bytes);
     for (uint64_t i = 0; i < plan->n; i++) {
@@ -722,6 +729,8 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
         plan->policy = nttx_plan::GOLDILOCKS;
     else if (q < (1ull << 61))
         plan->policy = nttx_plan::SHOUP61; // 8q <= 2^64: lazy butterflies
+    else if (q == nttx::Goldilocks::Q)
+        plan->policy = nttx_plan::GOLDILOCKS_CANONICAL; // Table::new_goldilock: the prime's own arithmetic
     else
         plan->policy = (q >> 63) ? nttx_plan::MONT_WIDE : nttx_plan::MONT;
     const uint64_t r_mod_q = (uint64_t)((((u128)1) << 64) % q);
@@ -749,6 +758,16 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
             plan->sctx_mul = plan->sctx;
             plan->sctx_mul.scale = pair_of((uint64_t)(((u128)n_inv_plain * r_mod_q) % q));
             plan->sctx_mul.scale1 = pair_of((uint64_t)(((u128)s1 * r_mod_q) % q));
+        }
+        if (plan->policy == nttx_plan::GOLDILOCKS_CANONICAL) {
+            const ntt::utils::MontgomeryTransformer<uint64_t> mt{k, 0, q};
+            plan->h_fwd_plain.resize(n);
+            plan->h_inv_plain.resize(n);
+            for (uint64_t i = 0; i < n; i++) {
+                plan->h_fwd_plain[i] = mt.reduce((u128)psi_bo[i]);
+                plan->h_inv_plain[i] = mt.reduce((u128)psi_inv_bo[i]);
+            }
+            plan->gctx = nttx::GoldilocksCtx{mt.reduce((u128)n_inv)};
         }
     } catch (const std::bad_alloc&) {
         delete plan;
