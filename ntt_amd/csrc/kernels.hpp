@@ -182,19 +182,24 @@ __device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const Src& w, const
 }
 
 // The reference's first sweep accepts any u64 (ntt.rs:125-127).  Residues are the common case:
-// each value is screened by its high word alone (one 32-bit compare) and only candidates take
-// the reduction.  Values are tested one by one so that work on the first loaded elements can
-// start while later loads are still in flight.
+// the largest high word of the thread's values is compared with the modulus's high word once,
+// and only when that screen fires (some value may be >= q) is each value tested and reduced.
 template <class A, int M>
 __device__ __forceinline__ void condition_all(uint64_t (&x)[M], const typename A::Ctx& c)
 {
     if constexpr (A::CONDITIONS_INPUT) {
         uint32_t qh = hi32(A::modulus(c));
         asm volatile("" : "+s"(qh)); // keep the screen a 32-bit compare (hipcc widens it otherwise)
+        uint32_t top = 0;
 #pragma unroll
-        for (int i = 0; i < M; i++) {
-            if (hi32(x[i]) >= qh)
-                x[i] = A::condition_input(x[i], c);
+        for (int i = 0; i < M; i++)
+            top = hi32(x[i]) > top ? hi32(x[i]) : top;
+        if (__builtin_expect(top >= qh, 0)) {
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                if (hi32(x[i]) >= qh)
+                    x[i] = A::condition_input(x[i], c);
+            }
         }
     }
 }
