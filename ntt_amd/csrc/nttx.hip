@@ -111,7 +111,12 @@ template <class A, bool FWD, bool CONTIG, int K1, int K2, bool XB = false>
 hipError_t launch_one(const PassParams& p, const typename A::Ctx& c, unsigned grid, hipStream_t s)
 {
     (void)hipGetLastError(); // drop any error an earlier, unrelated call left behind on this thread
-    hipLaunchKernelGGL((pass_kernel<A, FWD, CONTIG, K1, K2, XB>), dim3(grid), dim3(THREADS), 0, s, p, c);
+    // NTTX_DEBUG_EXTRA_LDS=<bytes>: unused dynamic LDS per workgroup, to lower occupancy in experiments
+    static const unsigned extra_lds = [] {
+        const char* e = std::getenv("NTTX_DEBUG_EXTRA_LDS");
+        return e ? (unsigned)std::atol(e) : 0u;
+    }();
+    hipLaunchKernelGGL((pass_kernel<A, FWD, CONTIG, K1, K2, XB>), dim3(grid), dim3(THREADS), extra_lds, s, p, c);
     return hipGetLastError();
 }
 
