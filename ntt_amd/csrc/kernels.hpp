@@ -13,7 +13,11 @@
 //   STRIDED tile: 2^K rows x (4096 / 2^K) adjacent columns, rows T elements apart; every
 //                 global access is a run of >= 128 contiguous bytes.  Used while T > 1.
 //   CONTIG  tile: 4096 contiguous elements (T = 1, the pass that holds the stride-1 stage);
-//                 moved between HBM and LDS with 16-byte-per-lane accesses.
+//                 moved between HBM and LDS with 16-byte-per-lane accesses.  For batches of 16
+//                 or more transforms the 8-stage CONTIG pass takes cross-batch tiles instead:
+//                 the same 256-element block of 16 consecutive transforms (see pass_8).
+// Global memory is addressed through buffer resources (scalar base + 32-bit lane offset) so
+// that element addresses cost no vector instructions: the passes are bound by VALU issue.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,9 +40,9 @@ enum : uint32_t {
     PASS_DEBUG_NO_TW = 16u,    // profiling aid (NTTX_DEBUG_NO_TW=1, with NO_MATH): skip the twiddle loads too
     PASS_DEBUG_NO_MATH_A = 32u, // profiling aids (NTTX_DEBUG_NO_MATH=A / B): skip one register round of the 8-stage pass
     PASS_DEBUG_NO_MATH_B = 64u,
-    PASS_OFFSET32 = 512u,      // every element of a tile lies within 2^31 bytes of the tile's first: buffer addressing
+    PASS_CROSS_BATCH = 128u,   // CONTIG 8-stage pass: a tile is the same 256-element block of 16 consecutive transforms
     PASS_POINTWISE = 256u,     // first pass of a backward transform: multiply by the vector at data2 first
-    PASS_CROSS_BATCH = 128u    // CONTIG 8-stage pass: a tile is the same 256-element block of 16 consecutive transforms
+    PASS_OFFSET32 = 512u       // every element of a tile lies within 2^31 bytes of the tile's first: buffer addressing
 };
 
 struct PassParams {
