@@ -68,3 +68,35 @@ def test_python_utils_mirror_matches_oracle():
     assert utils.mod_exp_u64(3, 200, 1000003) == pow(3, 200, 1000003)
     r = utils.find_nth_unity_root_u64(1 << 17, q61)
     assert pow(r, 1 << 17, q61) == 1 and pow(r, 1 << 16, q61) == q61 - 1
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/nttx.h compiles as C99 with -Wall -Werror and a C client links against libnttx.so
+    referencing every declared function (a Rust/C/Go FFI sees exactly this surface)."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    header = open(os.path.join(ROOT, "include", "nttx.h")).read()
+    names = sorted(set(re.findall(r"\b(nttx_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", header, flags=re.S))))
+    src = tmp_path / "client.c"
+    src.write_text('#include "nttx.h"\n#include <stdio.h>\nint main(void) {\n'
+                   '    const void *fns[] = {%s};\n'
+                   '    nttx_plan *plan = NULL;\n'
+                   '    int rc = nttx_plan_create_from_root(NTTX_MONT64, 7, 3, 8, NULL, 0, &plan);\n'
+                   '    printf("%%d %%s %%d\\n", rc, nttx_last_error(), (int)(sizeof fns / sizeof fns[0]));\n'
+                   '    return rc == NTTX_EINVAL && plan == NULL ? 0 : 1;\n}\n'
+                   % ", ".join("(const void *)%s" % n for n in names))
+    exe = tmp_path / "client"
+    libdir = os.path.join(ROOT, "ntt_amd")
+    inc = os.path.join(ROOT, "include")
+    only = tmp_path / "header_only.c"
+    only.write_text('#include "nttx.h"\nint nttx_header_ok;\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-c", str(only),
+                    "-o", str(tmp_path / "header_only.o")], check=True)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lnttx",
+                    "-Wl,-rpath," + libdir], check=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.split()[0] == "1" and res.stdout.strip().endswith(str(len(names)))
