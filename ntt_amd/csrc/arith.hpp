@@ -600,15 +600,17 @@ struct Goldilocks {
     static constexpr bool DEFERRED_CHECK = true;
     static constexpr uint32_t SUSPECT = 0xffffffffu;
 
+    // The fast butterflies write the high words to watch into `tops` (TOPS_CT / TOPS_GS of them);
+    // the caller folds them into one maximum with three-input max operations.
+    static constexpr int TOPS_CT = 3, TOPS_GS = 2, TOPS_GS_LAST = 3;
+
     // ntt_goldilock.rs:98-121
-    static NTTX_HD uint32_t ct_fast(uint64_t& a, uint64_t& b, const Tw& s, const Ctx&)
+    static NTTX_HD void ct_fast(uint64_t& a, uint64_t& b, const Tw& s, const Ctx&, uint32_t* tops)
     {
         const uint64_t u = a;
-        uint32_t t0, t1, t2;
-        const uint64_t v = mul_fast(b, s.w, t0);
-        a = add_fast(u, v, t1);
-        b = sub_fast(u, v, t2);
-        return max3(t0, t1, t2);
+        const uint64_t v = mul_fast(b, s.w, tops[0]);
+        a = add_fast(u, v, tops[1]);
+        b = sub_fast(u, v, tops[2]);
     }
     static NTTX_HD void ct_strict(uint64_t& a, uint64_t& b, const Tw& s, const Ctx&)
     {
@@ -618,13 +620,12 @@ struct Goldilocks {
     }
 
     // ntt_goldilock.rs:152-166
-    static NTTX_HD uint32_t gs_fast(uint64_t& a, uint64_t& b, const Tw& s, const Ctx&)
+    static NTTX_HD void gs_fast(uint64_t& a, uint64_t& b, const Tw& s, const Ctx&, uint32_t* tops)
     {
         const uint64_t u = a, v = b;
-        uint32_t t0, t1, t2;
-        a = add_fast(u, v, t0);
-        b = mul_fast(sub_fast(u, v, t2), s.w, t1);
-        return t0 > t1 ? t0 : t1;
+        uint32_t unused;
+        a = add_fast(u, v, tops[0]);
+        b = mul_fast(sub_fast(u, v, unused), s.w, tops[1]);
     }
     static NTTX_HD void gs_strict(uint64_t& a, uint64_t& b, const Tw& s, const Ctx&)
     {
@@ -636,13 +637,12 @@ struct Goldilocks {
     // last stage + mul_reduce(., n_inv) (ntt_goldilock.rs:177-179): both products are canonical.
     // `sf` = s * n_inv, computed once per twiddle by the caller (scaled()).
     static NTTX_HD Tw scaled(const Tw& s, const Ctx& c) { return Tw{mul_strict(s.w, c.n_inv)}; }
-    static NTTX_HD uint32_t gs_last_fast(uint64_t& a, uint64_t& b, const Tw& sf, const Ctx& c)
+    static NTTX_HD void gs_last_fast(uint64_t& a, uint64_t& b, const Tw& sf, const Ctx& c, uint32_t* tops)
     {
         const uint64_t u = a, v = b;
-        uint32_t t0, t1, t2, t3;
-        a = mul_fast(add_fast(u, v, t0), c.n_inv, t1);
-        b = mul_fast(sub_fast(u, v, t3), sf.w, t2);
-        return max3(t0, t1, t2);
+        uint32_t unused;
+        a = mul_fast(add_fast(u, v, tops[0]), c.n_inv, tops[1]);
+        b = mul_fast(sub_fast(u, v, unused), sf.w, tops[2]);
     }
     static NTTX_HD void gs_last_strict(uint64_t& a, uint64_t& b, const Tw& sf, const Ctx& c)
     {
@@ -655,7 +655,9 @@ struct Goldilocks {
     static NTTX_HD void ct(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
     {
         const uint64_t u = a, y = b;
-        if (__builtin_expect(ct_fast(a, b, s, c) == SUSPECT, 0)) {
+        uint32_t t[TOPS_CT];
+        ct_fast(a, b, s, c, t);
+        if (__builtin_expect(max3(t[0], t[1], t[2]) == SUSPECT, 0)) {
             a = u;
             b = y;
             ct_strict(a, b, s, c);
@@ -664,7 +666,9 @@ struct Goldilocks {
     static NTTX_HD void gs(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
     {
         const uint64_t u = a, y = b;
-        if (__builtin_expect(gs_fast(a, b, s, c) == SUSPECT, 0)) {
+        uint32_t t[TOPS_GS];
+        gs_fast(a, b, s, c, t);
+        if (__builtin_expect(max3(t[0], t[1], 0) == SUSPECT, 0)) {
             a = u;
             b = y;
             gs_strict(a, b, s, c);
@@ -674,7 +678,9 @@ struct Goldilocks {
     {
         const uint64_t u = a, y = b;
         const Tw sf = scaled(s, c);
-        if (__builtin_expect(gs_last_fast(a, b, sf, c) == SUSPECT, 0)) {
+        uint32_t t[TOPS_GS_LAST];
+        gs_last_fast(a, b, sf, c, t);
+        if (__builtin_expect(max3(t[0], t[1], t[2]) == SUSPECT, 0)) {
             a = u;
             b = y;
             gs_last_strict(a, b, sf, c);

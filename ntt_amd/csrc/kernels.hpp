@@ -110,7 +110,21 @@ __device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const Src& w, const
 #pragma unroll
             for (int i = 0; i < M; i++)
                 in[i] = x[i];
-            uint32_t suspect = 0;
+            // maximum of the words the fast butterflies ask to be watched, folded two at a time
+            uint32_t suspect = 0, held = 0;
+            bool holding = false;
+            auto watch = [&](const uint32_t* tops, int count) {
+#pragma unroll
+                for (int k = 0; k < count; k++) {
+                    if (holding) {
+                        suspect = A::max3(suspect, held, tops[k]);
+                        holding = false;
+                    } else {
+                        held = tops[k];
+                        holding = true;
+                    }
+                }
+            };
 #pragma unroll
             for (int b = 0; b < (1 << (u - 1)); b++) {
                 typename A::Tw s = w.get((1 << (u - 1)) + b);
@@ -119,12 +133,21 @@ __device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const Src& w, const
 #pragma unroll
                 for (int i = 0; i < half; i++) {
                     const int lo = b * 2 * half + i;
-                    const uint32_t t = FWD    ? A::ct_fast(x[lo], x[lo + half], s, c)
-                                       : last ? A::gs_last_fast(x[lo], x[lo + half], s, c)
-                                              : A::gs_fast(x[lo], x[lo + half], s, c);
-                    suspect = t > suspect ? t : suspect;
+                    uint32_t tops[3];
+                    if (FWD) {
+                        A::ct_fast(x[lo], x[lo + half], s, c, tops);
+                        watch(tops, A::TOPS_CT);
+                    } else if (last) {
+                        A::gs_last_fast(x[lo], x[lo + half], s, c, tops);
+                        watch(tops, A::TOPS_GS_LAST);
+                    } else {
+                        A::gs_fast(x[lo], x[lo + half], s, c, tops);
+                        watch(tops, A::TOPS_GS);
+                    }
                 }
             }
+            if (holding)
+                suspect = A::max3(suspect, held, 0);
             if (__builtin_expect(suspect == A::SUSPECT, 0)) {
 #pragma unroll
                 for (int b = 0; b < (1 << (u - 1)); b++) {
