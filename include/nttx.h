@@ -71,6 +71,17 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
 int nttx_plan_create_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n,
                                const int *devices, int n_devices, nttx_plan **out);
 
+/*
+ * Same as nttx_plan_create_from_root, but with k = q^-1 mod 2^64 for every odd modulus.  No
+ * counterpart in the reference: MontgomeryTransformer::from_modulus (utils.rs:148-152) lifts a
+ * negative Bezout coefficient by the modulus instead of 2^64 and so derives a k with k*q != 1 for
+ * about half of all moduli (12289, 65537, 786433 ...), for which the reference's transforms are
+ * wrong and nttx_plan_create / nttx_plan_create_from_root return NTTX_EINVAL.  With this entry
+ * point those moduli work; where the reference's k is right the plan is identical.
+ */
+int nttx_plan_create_from_root_exact_k(int kind, uint64_t q, uint64_t psi, uint64_t n,
+                                       const int *devices, int n_devices, nttx_plan **out);
+
 void nttx_plan_destroy(nttx_plan *plan);
 
 /* Read-back of what a plan holds (for parity tests against the reference's pub fields

@@ -15,6 +15,7 @@ _pint = C.POINTER(C.c_int)
 SYMBOLS = {
     "nttx_plan_create": (C.c_int, [C.c_int, _u64, _u64, _u64, _u64, _vp, _vp, _pint, C.c_int, C.POINTER(_vp)]),
     "nttx_plan_create_from_root": (C.c_int, [C.c_int, _u64, _u64, _u64, _pint, C.c_int, C.POINTER(_vp)]),
+    "nttx_plan_create_from_root_exact_k": (C.c_int, [C.c_int, _u64, _u64, _u64, _pint, C.c_int, C.POINTER(_vp)]),
     "nttx_plan_destroy": (None, [_vp]),
     "nttx_plan_info": (C.c_int, [_vp, _pint, _pu64, _pu64, _pu64, _pu64, _pint]),
     "nttx_plan_tables": (C.c_int, [_vp, _vp, _vp]),

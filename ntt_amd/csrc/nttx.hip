@@ -790,8 +790,8 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
     return NTTX_OK;
 }
 
-int nttx_plan_create_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n, const int* devices, int n_devices,
-                               nttx_plan** out)
+static int plan_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n, const int* devices, int n_devices,
+                          nttx_plan** out, bool exact_k)
 {
     if (!out)
         return fail(NTTX_EINVAL, "out is NULL");
@@ -802,7 +802,7 @@ int nttx_plan_create_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n, c
         if (kind == NTTX_MONT64) {
             if (q < 3 || psi == 0 || psi >= q)
                 return fail(NTTX_EINVAL, "need 0 < psi < q");
-            auto t = ntt::host::build_montgomery_tables(q, psi, n);
+            auto t = ntt::host::build_montgomery_tables(q, psi, n, exact_k);
             return nttx_plan_create(kind, q, t.montgomery.k, n, t.n_inv_montgomery, t.powers_psi_bo.data(),
                                     t.powers_psi_inv_bo.data(), devices, n_devices, out);
         } else if (kind == NTTX_GOLDILOCKS) {
@@ -820,6 +820,18 @@ int nttx_plan_create_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n, c
         return fail(NTTX_ENOMEM, "out of host memory");
     }
     return fail(NTTX_EINVAL, "unknown kind");
+}
+
+int nttx_plan_create_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n, const int* devices, int n_devices,
+                               nttx_plan** out)
+{
+    return plan_from_root(kind, q, psi, n, devices, n_devices, out, false);
+}
+
+int nttx_plan_create_from_root_exact_k(int kind, uint64_t q, uint64_t psi, uint64_t n, const int* devices,
+                                       int n_devices, nttx_plan** out)
+{
+    return plan_from_root(kind, q, psi, n, devices, n_devices, out, true);
 }
 
 void nttx_plan_destroy(nttx_plan* plan)

@@ -42,14 +42,17 @@ class _PlanTable(DFT):
     _kind = _lib.NTTX_MONT64
     _np_dtype = np.uint64
 
-    def __init__(self, q, psi, n, devices=None):
+    def __init__(self, q, psi, n, devices=None, exact_k=False):
         self.q, self.psi, self._n = q, psi, n
         self._plan = C.c_void_p()
+        # exact_k: q^-1 mod 2^64 for every odd modulus (the reference derives a wrong k for about half
+        # of them, utils.rs:148-152, and those are rejected otherwise); not the reference's behaviour
+        create = lib.nttx_plan_create_from_root_exact_k if exact_k else lib.nttx_plan_create_from_root
         if devices:
             arr = (C.c_int * len(devices))(*devices)
-            rc = lib.nttx_plan_create_from_root(self._kind, q, psi, n, arr, len(devices), C.byref(self._plan))
+            rc = create(self._kind, q, psi, n, arr, len(devices), C.byref(self._plan))
         else:
-            rc = lib.nttx_plan_create_from_root(self._kind, q, psi, n, None, 0, C.byref(self._plan))
+            rc = create(self._kind, q, psi, n, None, 0, C.byref(self._plan))
         _check(rc)
         self._devices = list(devices) if devices else [0]
 
@@ -184,12 +187,12 @@ class _PlanTable(DFT):
 class Table(_PlanTable):
     """`Table<u64>` (src/dft/ntt.rs): scalar Montgomery path."""
 
-    def __init__(self, modulus, root, n, devices=None):
-        super().__init__(modulus, root, n, devices)
+    def __init__(self, modulus, root, n, devices=None, exact_k=False):
+        super().__init__(modulus, root, n, devices, exact_k)
 
     @classmethod
-    def from_prime_and_root(cls, modulus, root, n, devices=None):  # ntt.rs:90
-        return cls(modulus, root, n, devices)
+    def from_prime_and_root(cls, modulus, root, n, devices=None, exact_k=False):  # ntt.rs:90
+        return cls(modulus, root, n, devices, exact_k)
 
     @classmethod
     def new(cls, devices=None):  # ntt.rs:55-57, 264-268

@@ -53,10 +53,13 @@ inline void fill_bit_reversed_powers(std::vector<uint64_t>& out, uint32_t log_n,
     }
 }
 
-inline MontgomeryTables build_montgomery_tables(uint64_t modulus, uint64_t root, uint64_t n)
+// exact_k: use MontgomeryTransformer::from_modulus_exact (not the reference's behaviour).
+inline MontgomeryTables build_montgomery_tables(uint64_t modulus, uint64_t root, uint64_t n, bool exact_k = false)
 {
     using utils::i128;
-    MontgomeryTables t{utils::MontgomeryTransformer<uint64_t>::from_modulus(modulus), 0, 0, {}, {}};
+    MontgomeryTables t{exact_k ? utils::MontgomeryTransformer<uint64_t>::from_modulus_exact(modulus)
+                               : utils::MontgomeryTransformer<uint64_t>::from_modulus(modulus),
+                       0, 0, {}, {}};
 
     const i128 n_inv_raw = std::get<1>(utils::egcd_i128((i128)n, (i128)modulus));
     const uint64_t n_inv = n_inv_raw < 0 ? (uint64_t)(n_inv_raw + (i128)modulus) : (uint64_t)n_inv_raw;

@@ -108,6 +108,20 @@ struct MontgomeryTransformer {
         return {k, r_square, modulus};
     }
 
+    // Same with k = modulus^-1 mod 2^64 for EVERY odd modulus: utils.rs:148-152 lifts a negative
+    // Bezout coefficient by `modulus` instead of 2^64, which leaves k * modulus != 1 (and with it
+    // wrong transforms) for about half of all moduli, 12289 and 65537 among them.  Not the
+    // reference's behaviour: an opt-in for callers who need those moduli.
+    static MontgomeryTransformer from_modulus_exact(O modulus)
+    {
+        MontgomeryTransformer t = from_modulus(modulus);
+        auto [gcd, x, y] = egcd_i128((i128)modulus, (i128)1 << 64);
+        (void)gcd;
+        (void)y;
+        t.k = (O)(uint64_t)(u128)x; // x mod 2^64
+        return t;
+    }
+
     // utils.rs:165-178
     O reduce(u128 a) const
     {

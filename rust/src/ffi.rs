@@ -21,6 +21,12 @@ extern "C" {
         kind: c_int, q: u64, psi: u64, n: u64,
         devices: *const c_int, n_devices: c_int, out: *mut *mut NttxPlan,
     ) -> c_int;
+    /// Not reference behaviour: k = q^-1 mod 2^64 for every odd q (utils.rs:148-152 gets about
+    /// half of all moduli wrong, and the two constructors above reject those).
+    pub fn nttx_plan_create_from_root_exact_k(
+        kind: c_int, q: u64, psi: u64, n: u64,
+        devices: *const c_int, n_devices: c_int, out: *mut *mut NttxPlan,
+    ) -> c_int;
     pub fn nttx_plan_destroy(plan: *mut NttxPlan);
     pub fn nttx_forward_host(plan: *const NttxPlan, data: *mut u64, batch: usize) -> c_int;
     pub fn nttx_backward_host(plan: *const NttxPlan, data: *mut u64, batch: usize) -> c_int;

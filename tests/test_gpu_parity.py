@@ -456,3 +456,54 @@ def test_device_entry_points_under_graph_capture(amd):
     ref.forward_inplace(want)
     assert np.array_equal(fwd_out[:n].cpu().numpy().view(np.uint64), want)
     assert np.array_equal(d.cpu().numpy().view(np.uint64), a)
+
+
+def test_exact_k_plans_for_moduli_the_reference_gets_wrong(amd):
+    """utils.rs:148-152 derives k with k*q != 1 for about half of all moduli (12289, 65537 ...):
+    the reference's transforms are wrong there and the ordinary constructors refuse them.  The
+    opt-in exact-k constructor must give the negacyclic NTT itself, checked against plain modular
+    arithmetic (closed form by stages) because the oracle reproduces the reference's k."""
+    def model_forward(a, psi, q, n):
+        logn = n.bit_length() - 1
+        w = [0] * n
+        x = 1
+        for i in range(n):
+            w[int(format(i, "0%db" % logn)[::-1], 2)] = x
+            x = x * psi % q
+        a = [int(v) % q for v in a]
+        t, m = n, 1
+        while m < n:
+            t //= 2
+            for i in range(m):
+                s = w[m + i]
+                for j in range(2 * i * t, 2 * i * t + t):
+                    u, v = a[j], a[j + t] * s % q
+                    a[j], a[j + t] = (u + v) % q, (u - v) % q
+            m *= 2
+        return np.array(a, dtype=np.uint64)
+
+    def root_of(q, order):
+        for g in range(2, q):
+            r = pow(g, (q - 1) // order, q)
+            if pow(r, order // 2, q) == q - 1:
+                return r
+
+    for q, n in ((12289, 1024), (65537, 4096), (786433, 256), (257, 16)):
+        psi = root_of(q, 2 * n)
+        with pytest.raises(amd.Panic):
+            amd.Table.from_prime_and_root(q, psi, n)
+        gpu = amd.Table.from_prime_and_root(q, psi, n, exact_k=True)
+        rng = np.random.default_rng(q)
+        a = rng.integers(0, 2**64, 3 * n, dtype=np.uint64)
+        a[:n] = rng.integers(0, q, n, dtype=np.uint64)
+        want = np.concatenate([model_forward(a[b * n:(b + 1) * n], psi, q, n) for b in range(3)])
+        got = a.copy()
+        gpu.forward_inplace_batch(got, 3)
+        assert np.array_equal(got, want), (q, n)
+        gpu.backward_inplace_batch(got, 3)
+        assert np.array_equal(got, a % np.uint64(q)), (q, n)
+    # where the reference's k is right the two constructors build the same plan
+    n = 256
+    t1 = amd.Table.from_prime_and_root(Q61, psi61_for(n), n)
+    t2 = amd.Table.from_prime_and_root(Q61, psi61_for(n), n, exact_k=True)
+    assert t1._info() == t2._info() and np.array_equal(t1.powers_psi_bo, t2.powers_psi_bo)
