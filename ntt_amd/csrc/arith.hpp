@@ -145,6 +145,10 @@ struct Shoup61 {
     static constexpr bool CONDITIONS_INPUT = true;
     static constexpr bool DEFERRED_CHECK = false;
     static NTTX_HD uint64_t modulus(const Ctx& c) { return c.q; }
+    // Inputs below this bound need no conditioning: both butterflies take values in [0, 4q), so
+    // the lazily reduced inputs the reference documents for its *_lazy methods ([0, 2q),
+    // ntt.rs:31-35, 45-49) run at full speed; the outputs are canonical either way.
+    static NTTX_HD uint64_t input_bound(const Ctx& c) { return c.q4; }
     struct Tw {
         uint32_t w0, w1, v0, v1;
     };
@@ -273,6 +277,7 @@ struct Mont {
     static constexpr bool CONDITIONS_INPUT = true;
     static constexpr bool DEFERRED_CHECK = false;
     static NTTX_HD uint64_t modulus(const Ctx& c) { return c.q; }
+    static NTTX_HD uint64_t input_bound(const Ctx& c) { return c.q; } // strict residues only
     struct Tw {
         uint64_t w;
     };
@@ -355,6 +360,7 @@ struct Goldilocks {
     using TwElem = uint64_t;
     static constexpr bool CONDITIONS_INPUT = false; // TableGoldilock has no input sweep
     static NTTX_HD uint64_t modulus(const Ctx&) { return 0xffffffff00000001ull; }
+    static NTTX_HD uint64_t input_bound(const Ctx&) { return 0xffffffff00000001ull; }
     struct Tw {
         uint64_t w;
     };

@@ -208,14 +208,15 @@ __device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const Src& w, const
     }
 }
 
-// The reference's first sweep accepts any u64 (ntt.rs:125-127).  Residues are the common case:
-// the largest high word of the thread's values is compared with the modulus's high word once,
-// and only when that screen fires (some value may be >= q) is each value tested and reduced.
+// The reference's first sweep accepts any u64 (ntt.rs:125-127).  Values the butterflies can take
+// as they are (below the policy's input_bound: residues, and for the lazy policy anything below
+// 4q) are the common case: the largest high word of the thread's values is compared with the
+// bound's high word once, and only when that screen fires is each value tested and reduced.
 template <class A, int M>
 __device__ __forceinline__ void condition_all(uint64_t (&x)[M], const typename A::Ctx& c)
 {
     if constexpr (A::CONDITIONS_INPUT) {
-        uint32_t qh = hi32(A::modulus(c));
+        uint32_t qh = hi32(A::input_bound(c));
         asm volatile("" : "+s"(qh)); // keep the screen a 32-bit compare (hipcc widens it otherwise)
         uint32_t top = 0;
 #pragma unroll

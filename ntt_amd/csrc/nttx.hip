@@ -33,6 +33,27 @@ int fail(int code, const std::string& msg)
                         std::string(#expr) + ": " + hipGetErrorString(e_));                        \
     } while (0)
 
+// No exception may cross the C boundary: entry points that allocate host memory run under this.
+template <class F>
+int guarded(F&& body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        try {
+            return fail(NTTX_ENOMEM, "out of host memory");
+        } catch (...) {
+            return NTTX_ENOMEM;
+        }
+    } catch (...) {
+        try {
+            return fail(NTTX_EINVAL, "unexpected exception");
+        } catch (...) {
+            return NTTX_EINVAL;
+        }
+    }
+}
+
 struct PassDesc {
     int k1, k2;
     bool contig;
@@ -682,6 +703,11 @@ int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
         HIP_TRY(hipMemcpy(plan->d_inv_perm[i], perm_inv.data(), bytes, hipMemcpyHostToDevice));
     }
     (void)hipSetDevice(prev);
+    // the derived tables now live on the devices; only the caller's tables stay for nttx_plan_tables
+    std::vector<nttx::TwPair>().swap(plan->h_fwd2);
+    std::vector<nttx::TwPair>().swap(plan->h_inv2);
+    std::vector<uint64_t>().swap(plan->h_fwd_plain);
+    std::vector<uint64_t>().swap(plan->h_inv_plain);
     return NTTX_OK;
 }
 
@@ -779,7 +805,7 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
         return fail(NTTX_ENOMEM, "out of host memory");
     }
     plan->passes = make_passes(logn);
-    int rc = finish_plan(plan, devices, n_devices);
+    int rc = guarded([&] { return finish_plan(plan, devices, n_devices); });
     if (rc != NTTX_OK) {
         std::string keep = g_err;
         nttx_plan_destroy(plan);
@@ -886,8 +912,14 @@ int nttx_plan_tables(const nttx_plan* plan, uint64_t* psi_bo_out, uint64_t* psi_
     return NTTX_OK;
 }
 
-int nttx_forward_host(const nttx_plan* plan, uint64_t* data, size_t batch) { return run_host(plan, data, batch, true); }
-int nttx_backward_host(const nttx_plan* plan, uint64_t* data, size_t batch) { return run_host(plan, data, batch, false); }
+int nttx_forward_host(const nttx_plan* plan, uint64_t* data, size_t batch)
+{
+    return guarded([&] { return run_host(plan, data, batch, true); });
+}
+int nttx_backward_host(const nttx_plan* plan, uint64_t* data, size_t batch)
+{
+    return guarded([&] { return run_host(plan, data, batch, false); });
+}
 
 int nttx_forward_device(const nttx_plan* plan, int device, void* dptr, size_t batch, void* hip_stream)
 {
@@ -902,7 +934,7 @@ int nttx_negacyclic_mul_host(const nttx_plan* plan, uint64_t* a, const uint64_t*
 {
     if (batch != 0 && !b)
         return fail(NTTX_EINVAL, "second operand is NULL");
-    return run_host(plan, a, batch, true, batch ? b : nullptr);
+    return guarded([&] { return run_host(plan, a, batch, true, batch ? b : nullptr); });
 }
 
 int nttx_negacyclic_mul_device(const nttx_plan* plan, int device, void* a, void* b, size_t batch, void* hip_stream)
@@ -958,11 +990,11 @@ int nttx_run_pass_device(const nttx_plan* plan, int device, void* dptr, size_t b
 
 int nttx_forward_distributed(const nttx_plan* plan, uint64_t* host_data, int n_shards)
 {
-    return run_distributed(plan, host_data, true, n_shards);
+    return guarded([&] { return run_distributed(plan, host_data, true, n_shards); });
 }
 int nttx_backward_distributed(const nttx_plan* plan, uint64_t* host_data, int n_shards)
 {
-    return run_distributed(plan, host_data, false, n_shards);
+    return guarded([&] { return run_distributed(plan, host_data, false, n_shards); });
 }
 
 int nttx_shard_geometry(const nttx_plan* plan, int n_shards, uint64_t* local_elems, uint64_t* rows, uint64_t* cols,

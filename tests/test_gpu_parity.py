@@ -166,6 +166,30 @@ def test_lazy_methods_equal_strict(amd):  # ntt.rs:31-35: LAZY is never read
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("logn", [4, 8, 12, 16, 20])
+def test_lazily_reduced_inputs(amd, logn):
+    """ntt.rs:31-35, 45-49 document [0, 2q) inputs for the lazy methods.  The kernels feed anything
+    below 4q to the butterflies unreduced; the outputs must still be the reference's, which
+    reduces every input first (ntt.rs:125-127).  Multiples of q up to 8q and their neighbours sit
+    on every threshold of the lazy arithmetic."""
+    n = 1 << logn
+    psi = psi61_for(n)
+    gpu, ref = amd.Table.from_prime_and_root(Q61, psi, n), orc.Table.from_prime_and_root(Q61, psi, n)
+    rng = np.random.default_rng(160 + logn)
+    res = orc.splitmix_residues(Q61, n, 16)
+    for span in (2, 4, 8):
+        raw = res + np.uint64(Q61) * rng.integers(0, span, n, dtype=np.uint64)  # 8q - 1 < 2^64
+        edge = np.array([m * Q61 + d for m in range(1, 8) for d in (-1, 0, 1)], dtype=np.uint64)[:n]
+        raw[:edge.size] = edge            # first operands of the first forward stage ...
+        if n >= 2 * edge.size:
+            raw[-edge.size:] = edge[::-1]  # ... and second operands
+        for fn in ("forward_inplace_lazy", "backward_inplace_lazy", "forward_inplace", "backward_inplace"):
+            a, w = raw.copy(), raw.copy()
+            getattr(gpu, fn)(a)
+            getattr(ref, fn)(w)
+            assert np.array_equal(a, w), (fn, span)
+
+
 def test_u32_compatible(amd):  # ntt.rs:66-68
     gpu, ref = amd.Table.new_u32_compatible(), orc.Table.new_u32_compatible()
     _batch_check(gpu, ref, 4293918721, 1 << 16, 2, 16)
