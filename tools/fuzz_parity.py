@@ -42,6 +42,12 @@ def inputs(q, count, style):
         return rng.integers(0, q, count, dtype=np.uint64)
     if style == 1:
         return rng.integers(0, 2**64, count, dtype=np.uint64)
+    if style == 3:     # lazily reduced: residue + a small multiple of q (wraps past 2^64 for 64-bit q)
+        a = rng.integers(0, q, count, dtype=np.uint64) + np.uint64(q) * rng.integers(0, 8, count, dtype=np.uint64)
+        near = rng.random(count) < 0.05
+        a[near] = (np.uint64(q) * rng.integers(1, 9, int(near.sum()), dtype=np.uint64)
+                   + rng.integers(0, 3, int(near.sum()), dtype=np.uint64) - np.uint64(1))
+        return a
     a = rng.integers(0, q, count, dtype=np.uint64)
     edges = np.array([0, 1, q - 1, q, (q + 1) % 2**64, 2**64 - 1, 2**32 - 1, 2**32, q - 2, 4 * q % 2**64, 2**63],
                      dtype=np.uint64)
@@ -60,7 +66,7 @@ while time.time() < t_end:
     batch = int(rng.integers(1, 70 if logn <= 14 else (24 if logn <= 16 else 3)))
     gpu, ref, q = get(kind, logn)
     mode = int(rng.integers(0, 4))
-    style = int(rng.integers(0, 3))
+    style = int(rng.integers(0, 4))
     a = inputs(q, n * batch, style)
     tag = (kind, logn, batch, mode, style)
     if mode == 0:      # forward
