@@ -100,6 +100,11 @@ int nttx_plan_tables(const nttx_plan *plan, uint64_t *psi_bo_out, uint64_t *psi_
  * Copies to the plan's devices, splits the batch evenly across them, transforms, copies back.
  * Forward: natural order in, bit-reversed order out.  Backward: bit-reversed in, natural out,
  * scaled by n^-1.
+ * A share of 16 MiB or more per device is streamed in chunks of whole transforms (2 to 16 MiB)
+ * through pinned memory, host threads copying between the caller's slice and the pinned chunks
+ * (NTTX_HOST_COPY_THREADS, default 8) while uploads, kernels and downloads of neighbouring
+ * chunks overlap; the plan then keeps 128 MiB of pinned host memory and 64 MiB of device memory
+ * per device until it is destroyed.  Smaller calls copy straight from the caller's memory.
  */
 int nttx_forward_host(const nttx_plan *plan, uint64_t *data, size_t batch);
 int nttx_backward_host(const nttx_plan *plan, uint64_t *data, size_t batch);

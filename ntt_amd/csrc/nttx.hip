@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -9,6 +10,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nttx.h"
@@ -60,6 +62,90 @@ struct PassDesc {
     uint32_t s0;
 };
 
+// Host threads that move a caller's pageable slice to and from pinned staging memory.  One
+// memcpy stream per core is far below what a PCIe 5 x16 link carries; several in parallel keep
+// up with it (measured on the MI355X host: 1 thread 27 GB/s, 4 threads 48 GB/s).
+class CopyPool {
+    struct Piece {
+        char* dst;
+        const char* src;
+        size_t bytes;
+    };
+    static constexpr size_t PIECE_BYTES = 2u << 20;
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable wake, all_done;
+    std::vector<Piece> pieces; // guarded by m, as are the counters below
+    size_t next = 0, finished = 0;
+    uint64_t generation = 0;
+    bool stop = false;
+
+    void drain(std::unique_lock<std::mutex>& lk)
+    {
+        while (next < pieces.size()) {
+            const Piece p = pieces[next++];
+            lk.unlock();
+            std::memcpy(p.dst, p.src, p.bytes);
+            lk.lock();
+            if (++finished == pieces.size())
+                all_done.notify_all();
+        }
+    }
+    void work()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        uint64_t seen = 0;
+        for (;;) {
+            wake.wait(lk, [&] { return stop || generation != seen; });
+            if (stop)
+                return;
+            seen = generation;
+            drain(lk);
+        }
+    }
+    void add(void* dst, const void* src, size_t bytes)
+    {
+        for (size_t off = 0; off < bytes; off += PIECE_BYTES)
+            pieces.push_back(Piece{static_cast<char*>(dst) + off, static_cast<const char*>(src) + off,
+                                   std::min(PIECE_BYTES, bytes - off)});
+    }
+
+public:
+    explicit CopyPool(int threads)
+    {
+        for (int i = 1; i < threads; i++) // the calling thread copies too
+            workers.emplace_back([this] { work(); });
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        wake.notify_all();
+        for (auto& w : workers)
+            w.join();
+    }
+    CopyPool(const CopyPool&) = delete;
+    CopyPool& operator=(const CopyPool&) = delete;
+
+    // Performs both copies (either may be empty), split over all threads; returns when done.
+    void run(void* d0, const void* s0, size_t n0, void* d1, const void* s1, size_t n1)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        pieces.clear();
+        next = finished = 0;
+        add(d0, s0, n0);
+        add(d1, s1, n1);
+        if (pieces.empty())
+            return;
+        generation++;
+        wake.notify_all();
+        drain(lk);
+        all_done.wait(lk, [&] { return finished == pieces.size(); });
+    }
+};
+
 } // namespace
 
 struct nttx_plan {
@@ -89,6 +175,17 @@ struct nttx_plan {
         hipStream_t stream = nullptr;
         void* buf = nullptr;
         size_t cap = 0;
+        // Large batches are streamed through pinned memory in chunks (run_staged): STAGES chunks
+        // in flight, uploads and downloads on separate streams so both directions of the link work.
+        static constexpr int STAGES = 4;
+        bool staged_ready = false;
+        hipStream_t down = nullptr;
+        char* pin_in[STAGES] = {};
+        char* pin_out[STAGES] = {};
+        void* dev[STAGES] = {};
+        hipEvent_t computed[STAGES] = {};
+        hipEvent_t downloaded[STAGES] = {};
+        std::unique_ptr<CopyPool> pool;
     };
     mutable std::vector<std::unique_ptr<HostSlot>> host_slots;
 };
@@ -538,8 +635,156 @@ int enqueue_product(const nttx_plan* plan, int slot, uint64_t* a, uint64_t* b, s
 
 // Staging buffers up to this size stay allocated between host-slice calls.
 constexpr size_t HOST_SLOT_KEEP_BYTES = 256ull << 20;
+// Calls that move at least STAGE_MIN_BYTES per device stream the batch through pinned memory in
+// chunks of whole transforms of at most STAGE_CHUNK_BYTES (transforms larger than that take the
+// plain path), HostSlot::STAGES chunks in flight.  The runtime's own copies from pageable memory
+// run one direction after the other at 28 GB/s up and 17 GB/s down on the MI355X host.
+constexpr size_t STAGE_CHUNK_BYTES = 16ull << 20;
+constexpr size_t STAGE_MIN_BYTES = 16ull << 20;
+
+int copy_threads()
+{
+    static const int v = [] {
+        const char* e = std::getenv("NTTX_HOST_COPY_THREADS");
+        long t = e ? std::atol(e) : 8;
+        return (int)std::min(64L, std::max(1L, t));
+    }();
+    return v;
+}
+
+// Pinned chunks, device chunks, events and copy threads of a slot; kept until the plan goes.
+// The slot's device is current and its lock is held.
+int ensure_staging(nttx_plan::HostSlot& s)
+{
+    if (s.staged_ready)
+        return NTTX_OK;
+    if (!s.down)
+        HIP_TRY(hipStreamCreateWithFlags(&s.down, hipStreamNonBlocking));
+    for (int i = 0; i < nttx_plan::HostSlot::STAGES; i++) {
+        if (!s.pin_in[i])
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.pin_in[i]), STAGE_CHUNK_BYTES, hipHostMallocDefault));
+        if (!s.pin_out[i])
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.pin_out[i]), STAGE_CHUNK_BYTES, hipHostMallocDefault));
+        if (!s.dev[i])
+            HIP_TRY(hipMalloc(&s.dev[i], STAGE_CHUNK_BYTES));
+        if (!s.computed[i])
+            HIP_TRY(hipEventCreateWithFlags(&s.computed[i], hipEventDisableTiming));
+        if (!s.downloaded[i])
+            HIP_TRY(hipEventCreateWithFlags(&s.downloaded[i], hipEventDisableTiming));
+    }
+    if (!s.pool)
+        s.pool.reset(new CopyPool(copy_threads()));
+    s.staged_ready = true;
+    return NTTX_OK;
+}
+
+// Transforms `count` vectors at `data` (host) chunk by chunk, D = STAGES chunks in flight.  In
+// step t the host threads fill the pinned input of chunk t and empty the pinned output of chunk
+// t - D while the device uploads, transforms and downloads the chunks in between (upload +
+// kernels on the slot's stream, downloads on a second stream).  Buffers t mod D are reused every
+// D-th chunk; the one host wait per step (download of chunk t - D complete) frees all three.
+int run_staged(const nttx_plan* plan, int slot_index, nttx_plan::HostSlot& s, uint64_t* data, size_t count, bool fwd)
+{
+    const size_t vec_bytes = sizeof(uint64_t) << plan->logn;
+    // about eight chunks per call, between 2 MiB and the size of the pinned buffers
+    const size_t chunk_bytes = std::min(STAGE_CHUNK_BYTES, std::max<size_t>(2u << 20, count * vec_bytes / 8));
+    const size_t per = std::max<size_t>(1, chunk_bytes / vec_bytes);
+    const size_t chunks = (count + per - 1) / per;
+    auto first_of = [&](size_t c) { return c * per; };
+    auto count_of = [&](size_t c) { return std::min(per, count - c * per); };
+    auto body = [&]() -> int {
+        constexpr size_t D = nttx_plan::HostSlot::STAGES;
+        for (size_t t = 0; t < chunks + D; t++) {
+            const int b = (int)(t % D);
+            const bool in = t < chunks, out = t >= D && t - D < chunks;
+            if (out)
+                HIP_TRY(hipEventSynchronize(s.downloaded[b]));
+            s.pool->run(s.pin_in[b], in ? data + (first_of(t) << plan->logn) : nullptr, in ? count_of(t) * vec_bytes : 0,
+                        out ? data + (first_of(t - D) << plan->logn) : nullptr, s.pin_out[b],
+                        out ? count_of(t - D) * vec_bytes : 0);
+            if (!in)
+                continue;
+            const size_t bytes = count_of(t) * vec_bytes;
+            HIP_TRY(hipMemcpyAsync(s.dev[b], s.pin_in[b], bytes, hipMemcpyHostToDevice, s.stream));
+            int rc = enqueue(plan, slot_index, static_cast<uint64_t*>(s.dev[b]), count_of(t), fwd, s.stream);
+            if (rc != NTTX_OK)
+                return rc;
+            HIP_TRY(hipEventRecord(s.computed[b], s.stream));
+            HIP_TRY(hipStreamWaitEvent(s.down, s.computed[b], 0));
+            HIP_TRY(hipMemcpyAsync(s.pin_out[b], s.dev[b], bytes, hipMemcpyDeviceToHost, s.down));
+            HIP_TRY(hipEventRecord(s.downloaded[b], s.down));
+        }
+        return NTTX_OK;
+    };
+    const int rc = body();
+    // nothing of this call may still be in flight when the slot is handed to the next one
+    const hipError_t e1 = hipStreamSynchronize(s.stream), e2 = hipStreamSynchronize(s.down);
+    if (rc == NTTX_OK && (e1 != hipSuccess || e2 != hipSuccess))
+        return fail(NTTX_EHIP, std::string("stream synchronisation: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    return rc;
+}
+
+// One device's share of a host-slice call: `count` vectors at `data` (and at `other` for a
+// negacyclic product data <- data * other; fwd is ignored then).
+int run_host_on(const nttx_plan* plan, size_t i, uint64_t* data, size_t count, bool fwd, const uint64_t* other)
+{
+    const size_t vec_bytes = (count << plan->logn) * sizeof(uint64_t);
+    const size_t bytes = other ? 2 * vec_bytes : vec_bytes;
+    HIP_TRY(hipSetDevice(plan->devices[i]));
+    nttx_plan::HostSlot& s = *plan->host_slots[i];
+    std::lock_guard<std::mutex> guard(s.lock);
+    if (!s.stream)
+        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    static const bool no_staging = std::getenv("NTTX_NO_HOST_STAGING") != nullptr;
+    if (!other && !no_staging && vec_bytes >= STAGE_MIN_BYTES && (sizeof(uint64_t) << plan->logn) <= STAGE_CHUNK_BYTES) {
+        int rc = ensure_staging(s);
+        if (rc != NTTX_OK)
+            return rc;
+        return run_staged(plan, (int)i, s, data, count, fwd);
+    }
+    uint64_t* d = nullptr;
+    bool own = false; // d was allocated for this call (too large to keep)
+    if (bytes <= s.cap) {
+        d = static_cast<uint64_t*>(s.buf);
+    } else if (bytes <= HOST_SLOT_KEEP_BYTES) {
+        if (s.buf)
+            (void)hipFree(s.buf);
+        s.buf = nullptr;
+        s.cap = 0;
+        HIP_TRY(hipMalloc(&s.buf, bytes));
+        s.cap = bytes;
+        d = static_cast<uint64_t*>(s.buf);
+    } else {
+        HIP_TRY(hipMalloc(&d, bytes));
+        own = true;
+    }
+    auto body = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(d, data, vec_bytes, hipMemcpyHostToDevice, s.stream));
+        int r;
+        if (other) {
+            uint64_t* d2 = d + (count << plan->logn);
+            HIP_TRY(hipMemcpyAsync(d2, other, vec_bytes, hipMemcpyHostToDevice, s.stream));
+            r = enqueue_product(plan, (int)i, d, d2, count, s.stream);
+        } else {
+            r = enqueue(plan, (int)i, d, count, fwd, s.stream);
+        }
+        if (r != NTTX_OK)
+            return r;
+        HIP_TRY(hipMemcpyAsync(data, d, vec_bytes, hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(hipStreamSynchronize(s.stream));
+        return NTTX_OK;
+    };
+    const int rc = body();
+    if (rc != NTTX_OK)
+        (void)hipStreamSynchronize(s.stream);
+    if (own)
+        (void)hipFree(d);
+    return rc;
+}
 
 // `other` != NULL: negacyclic product data <- data * other instead of a transform (fwd ignored).
+// The batch is split evenly over the plan's devices; with several devices each share runs on a
+// host thread of its own.
 int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd, const uint64_t* other = nullptr)
 {
     if (!plan)
@@ -548,79 +793,50 @@ int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd, cons
         return NTTX_OK;
     if (!data)
         return fail(NTTX_EINVAL, "data is NULL");
+    const uint64_t total = (uint64_t)batch << plan->logn;
+    if ((total >> plan->logn) != batch || total > (1ull << 40))
+        return fail(NTTX_EINVAL, "batch * n is too large");
     const size_t ndev = plan->devices.size();
     const size_t per = (batch + ndev - 1) / ndev;
-    struct Work {
-        nttx_plan::HostSlot* slot = nullptr;
-        std::unique_lock<std::mutex> guard;
-        uint64_t* d = nullptr;
-        bool own = false; // d was allocated for this call (too large to keep)
-        size_t first = 0, count = 0;
-    };
-    std::vector<Work> work(ndev);
-    int rc = NTTX_OK;
     int prev = 0;
     (void)hipGetDevice(&prev);
-
-    auto body = [&]() -> int {
-        for (size_t i = 0; i < ndev; i++) {
-            Work& w = work[i];
-            w.first = i * per;
-            if (w.first >= batch)
-                break;
-            w.count = std::min(per, batch - w.first);
-            const size_t vec_bytes = (w.count << plan->logn) * sizeof(uint64_t);
-            const size_t bytes = other ? 2 * vec_bytes : vec_bytes;
-            HIP_TRY(hipSetDevice(plan->devices[i]));
-            w.slot = plan->host_slots[i].get();
-            w.guard = std::unique_lock<std::mutex>(w.slot->lock);
-            if (!w.slot->stream)
-                HIP_TRY(hipStreamCreateWithFlags(&w.slot->stream, hipStreamNonBlocking));
-            if (bytes <= w.slot->cap) {
-                w.d = static_cast<uint64_t*>(w.slot->buf);
-            } else if (bytes <= HOST_SLOT_KEEP_BYTES) {
-                if (w.slot->buf)
-                    (void)hipFree(w.slot->buf);
-                w.slot->buf = nullptr;
-                w.slot->cap = 0;
-                HIP_TRY(hipMalloc(&w.slot->buf, bytes));
-                w.slot->cap = bytes;
-                w.d = static_cast<uint64_t*>(w.slot->buf);
-            } else {
-                HIP_TRY(hipMalloc(&w.d, bytes));
-                w.own = true;
+    int rc = NTTX_OK;
+    if (ndev == 1 || batch <= per) {
+        rc = run_host_on(plan, 0, data, batch, fwd, other);
+    } else {
+        std::vector<int> rcs(ndev, NTTX_OK);
+        std::vector<std::string> msgs(ndev);
+        std::vector<std::thread> threads;
+        bool spawned = true;
+        try {
+            for (size_t i = 0; i < ndev && i * per < batch; i++) {
+                const size_t first = i * per, count = std::min(per, batch - first);
+                if (i + 1 == ndev || (i + 1) * per >= batch) { // the last share runs on this thread
+                    rcs[i] = run_host_on(plan, i, data + (first << plan->logn), count, fwd,
+                                         other ? other + (first << plan->logn) : nullptr);
+                    if (rcs[i] != NTTX_OK)
+                        msgs[i] = g_err;
+                    break;
+                }
+                threads.emplace_back([&, i, first, count] {
+                    rcs[i] = guarded([&] {
+                        return run_host_on(plan, i, data + (first << plan->logn), count, fwd,
+                                           other ? other + (first << plan->logn) : nullptr);
+                    });
+                    if (rcs[i] != NTTX_OK)
+                        msgs[i] = g_err; // thread-local: carried back to the caller's thread below
+                });
             }
-            hipStream_t st = w.slot->stream;
-            HIP_TRY(hipMemcpyAsync(w.d, data + (w.first << plan->logn), vec_bytes, hipMemcpyHostToDevice, st));
-            int r;
-            if (other) {
-                uint64_t* d2 = w.d + (w.count << plan->logn);
-                HIP_TRY(hipMemcpyAsync(d2, other + (w.first << plan->logn), vec_bytes, hipMemcpyHostToDevice, st));
-                r = enqueue_product(plan, (int)i, w.d, d2, w.count, st);
-            } else {
-                r = enqueue(plan, (int)i, w.d, w.count, fwd, st);
-            }
-            if (r != NTTX_OK)
-                return r;
-            HIP_TRY(hipMemcpyAsync(data + (w.first << plan->logn), w.d, vec_bytes, hipMemcpyDeviceToHost, st));
+        } catch (...) {
+            spawned = false;
         }
-        for (size_t i = 0; i < ndev; i++) {
-            if (!work[i].slot)
-                continue;
-            HIP_TRY(hipSetDevice(plan->devices[i]));
-            HIP_TRY(hipStreamSynchronize(work[i].slot->stream));
-        }
-        return NTTX_OK;
-    };
-    rc = body();
-    for (size_t i = 0; i < ndev; i++) {
-        if (!work[i].slot)
-            continue;
-        (void)hipSetDevice(plan->devices[i]);
-        if (work[i].slot->stream)
-            (void)hipStreamSynchronize(work[i].slot->stream);
-        if (work[i].own && work[i].d)
-            (void)hipFree(work[i].d);
+        for (auto& t : threads)
+            t.join();
+        if (!spawned)
+            rc = fail(NTTX_ENOMEM, "could not start a host thread");
+        for (size_t i = 0; i < ndev; i++)
+            if (rcs[i] != NTTX_OK && rc == NTTX_OK)
+                rc = fail(rcs[i], msgs[i]);
     }
     (void)hipSetDevice(prev);
     return rc;
@@ -881,6 +1097,21 @@ void nttx_plan_destroy(nttx_plan* plan)
                 (void)hipStreamDestroy(plan->host_slots[i]->stream);
             if (plan->host_slots[i]->buf)
                 (void)hipFree(plan->host_slots[i]->buf);
+            nttx_plan::HostSlot& hs = *plan->host_slots[i];
+            if (hs.down)
+                (void)hipStreamDestroy(hs.down);
+            for (int b = 0; b < nttx_plan::HostSlot::STAGES; b++) {
+                if (hs.pin_in[b])
+                    (void)hipHostFree(hs.pin_in[b]);
+                if (hs.pin_out[b])
+                    (void)hipHostFree(hs.pin_out[b]);
+                if (hs.dev[b])
+                    (void)hipFree(hs.dev[b]);
+                if (hs.computed[b])
+                    (void)hipEventDestroy(hs.computed[b]);
+                if (hs.downloaded[b])
+                    (void)hipEventDestroy(hs.downloaded[b]);
+            }
         }
     }
     (void)hipSetDevice(prev);

@@ -376,6 +376,38 @@ def test_baseline_sizes_device_resident(amd, workload):
     assert torch.equal(data, original)
 
 
+@pytest.mark.parametrize("kind,logn,batch", [("mont", 16, 160), ("mont", 16, 37), ("goldilocks", 20, 9), ("goldilocks", 20, 2), ("mont", 14, 600),
+                                             ("mont", 12, 2100)])
+def test_large_host_batches_streamed_in_chunks(amd, kind, logn, batch):
+    """Host batches of 16 MiB and more per device go through pinned chunks of whole transforms (four
+    in flight, ragged last chunk); results must equal the per-vector oracle and the plain path's."""
+    n = 1 << logn
+    assert n * batch * 8 >= 16 << 20
+    if kind == "mont":
+        q, psi = Q61, psi61_for(n)
+        gpu, ref = amd.Table.from_prime_and_root(q, psi, n), orc.Table.from_prime_and_root(q, psi, n)
+    else:
+        q, psi = QGL, psigl_for(n)
+        gpu, ref = amd.TableGoldilock.from_root(psi, n), orc.TableGoldilock.from_root(psi, n)
+    a0 = orc.splitmix_residues(q, n * batch, 4000 + logn)
+    got = a0.copy()
+    gpu.forward_inplace_batch(got, batch)
+    # the oracle on the first, the last and a middle transform; transforms on either side of every
+    # chunk boundary against the same vector sent alone (a single vector takes the plain path)
+    for b in sorted({0, batch // 2, batch - 1}):
+        want = a0[b * n:(b + 1) * n].copy()
+        ref.forward_inplace(want)
+        assert np.array_equal(got[b * n:(b + 1) * n], want), "forward, transform %d" % b
+    per = max(1, min(16 << 20, max(2 << 20, batch * n)) // (8 * n))  # chunk: an eighth of the call, 2..16 MiB
+    edges = {b for c in range(0, batch, per) for b in (c - 1, c, c + 1) if 0 <= b < batch} | {batch - 1}
+    for b in sorted(edges)[:24]:
+        alone = a0[b * n:(b + 1) * n].copy()
+        gpu.forward_inplace(alone)
+        assert np.array_equal(alone, got[b * n:(b + 1) * n]), "forward, transform %d alone" % b
+    gpu.backward_inplace_batch(got, batch)
+    assert np.array_equal(got, a0), "round trip"
+
+
 def test_abi_argument_checks(amd):
     """Status codes of the C ABI for arguments the Python layer normally screens."""
     import ctypes as C

@@ -9,7 +9,7 @@ n = 1 << 16
 q = 0x1FFFFFFFFFE00001
 t = ntt_amd.Table.new()
 rng = np.random.default_rng(1)
-for batch in (1, 64, 1024, 4096):
+for batch in (1, 16, 32, 64, 256, 1024, 4096):
     a = rng.integers(0, q, batch * n, dtype=np.uint64)
     t.forward_inplace_batch(a, batch)
     t.backward_inplace_batch(a, batch)
