@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -129,14 +130,19 @@ public:
     CopyPool(const CopyPool&) = delete;
     CopyPool& operator=(const CopyPool&) = delete;
 
-    // Performs both copies (either may be empty), split over all threads; returns when done.
-    void run(void* d0, const void* s0, size_t n0, void* d1, const void* s1, size_t n1)
+    struct Copy {
+        void* dst;
+        const void* src;
+        size_t bytes;
+    };
+    // Performs the copies (any may be empty), split over all threads; returns when they are done.
+    void run(std::initializer_list<Copy> copies)
     {
         std::unique_lock<std::mutex> lk(m);
         pieces.clear();
         next = finished = 0;
-        add(d0, s0, n0);
-        add(d1, s1, n1);
+        for (const Copy& c : copies)
+            add(c.dst, c.src, c.bytes);
         if (pieces.empty())
             return;
         generation++;
@@ -683,11 +689,13 @@ int ensure_staging(nttx_plan::HostSlot& s)
 // t - D while the device uploads, transforms and downloads the chunks in between (upload +
 // kernels on the slot's stream, downloads on a second stream).  Buffers t mod D are reused every
 // D-th chunk; the one host wait per step (download of chunk t - D complete) frees all three.
-int run_staged(const nttx_plan* plan, int slot_index, nttx_plan::HostSlot& s, uint64_t* data, size_t count, bool fwd)
+int run_staged(const nttx_plan* plan, int slot_index, nttx_plan::HostSlot& s, uint64_t* data, size_t count, bool fwd,
+               const uint64_t* other)
 {
     const size_t vec_bytes = sizeof(uint64_t) << plan->logn;
+    const size_t room = other ? STAGE_CHUNK_BYTES / 2 : STAGE_CHUNK_BYTES; // a product keeps both operands in a chunk
     // about eight chunks per call, between 2 MiB and the size of the pinned buffers
-    const size_t chunk_bytes = std::min(STAGE_CHUNK_BYTES, std::max<size_t>(2u << 20, count * vec_bytes / 8));
+    const size_t chunk_bytes = std::min(room, std::max<size_t>(2u << 20, count * vec_bytes / 8));
     const size_t per = std::max<size_t>(1, chunk_bytes / vec_bytes);
     const size_t chunks = (count + per - 1) / per;
     auto first_of = [&](size_t c) { return c * per; };
@@ -699,19 +707,23 @@ int run_staged(const nttx_plan* plan, int slot_index, nttx_plan::HostSlot& s, ui
             const bool in = t < chunks, out = t >= D && t - D < chunks;
             if (out)
                 HIP_TRY(hipEventSynchronize(s.downloaded[b]));
-            s.pool->run(s.pin_in[b], in ? data + (first_of(t) << plan->logn) : nullptr, in ? count_of(t) * vec_bytes : 0,
-                        out ? data + (first_of(t - D) << plan->logn) : nullptr, s.pin_out[b],
-                        out ? count_of(t - D) * vec_bytes : 0);
+            const size_t in_bytes = in ? count_of(t) * vec_bytes : 0;
+            const size_t out_bytes = out ? count_of(t - D) * vec_bytes : 0;
+            s.pool->run({{s.pin_in[b], in ? data + (first_of(t) << plan->logn) : nullptr, in_bytes},
+                         {s.pin_in[b] + in_bytes, (in && other) ? other + (first_of(t) << plan->logn) : nullptr,
+                          other ? in_bytes : 0},
+                         {out ? data + (first_of(t - D) << plan->logn) : nullptr, s.pin_out[b], out_bytes}});
             if (!in)
                 continue;
-            const size_t bytes = count_of(t) * vec_bytes;
-            HIP_TRY(hipMemcpyAsync(s.dev[b], s.pin_in[b], bytes, hipMemcpyHostToDevice, s.stream));
-            int rc = enqueue(plan, slot_index, static_cast<uint64_t*>(s.dev[b]), count_of(t), fwd, s.stream);
+            uint64_t* const d = static_cast<uint64_t*>(s.dev[b]);
+            HIP_TRY(hipMemcpyAsync(d, s.pin_in[b], other ? 2 * in_bytes : in_bytes, hipMemcpyHostToDevice, s.stream));
+            int rc = other ? enqueue_product(plan, slot_index, d, d + (count_of(t) << plan->logn), count_of(t), s.stream)
+                           : enqueue(plan, slot_index, d, count_of(t), fwd, s.stream);
             if (rc != NTTX_OK)
                 return rc;
             HIP_TRY(hipEventRecord(s.computed[b], s.stream));
             HIP_TRY(hipStreamWaitEvent(s.down, s.computed[b], 0));
-            HIP_TRY(hipMemcpyAsync(s.pin_out[b], s.dev[b], bytes, hipMemcpyDeviceToHost, s.down));
+            HIP_TRY(hipMemcpyAsync(s.pin_out[b], d, in_bytes, hipMemcpyDeviceToHost, s.down));
             HIP_TRY(hipEventRecord(s.downloaded[b], s.down));
         }
         return NTTX_OK;
@@ -736,11 +748,12 @@ int run_host_on(const nttx_plan* plan, size_t i, uint64_t* data, size_t count, b
     if (!s.stream)
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     static const bool no_staging = std::getenv("NTTX_NO_HOST_STAGING") != nullptr;
-    if (!other && !no_staging && vec_bytes >= STAGE_MIN_BYTES && (sizeof(uint64_t) << plan->logn) <= STAGE_CHUNK_BYTES) {
+    if (!no_staging && vec_bytes >= STAGE_MIN_BYTES &&
+        (sizeof(uint64_t) << plan->logn) <= (other ? STAGE_CHUNK_BYTES / 2 : STAGE_CHUNK_BYTES)) {
         int rc = ensure_staging(s);
         if (rc != NTTX_OK)
             return rc;
-        return run_staged(plan, (int)i, s, data, count, fwd);
+        return run_staged(plan, (int)i, s, data, count, fwd, other);
     }
     uint64_t* d = nullptr;
     bool own = false; // d was allocated for this call (too large to keep)

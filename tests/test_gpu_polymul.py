@@ -113,6 +113,16 @@ def test_square_and_overlap(amd):
     gpu.negacyclic_mul_inplace(d, d)
     torch.cuda.synchronize()
     assert np.array_equal(d.cpu().numpy().view(np.uint64), want)
+    # a host batch large enough to be streamed in chunks, squared in place: same bits as the device path
+    batch = 600
+    a = orc.splitmix_residues(q, n * batch, 301)
+    d = torch.from_numpy(a.view(np.int64).copy()).cuda()
+    gpu.negacyclic_mul_inplace(d, d)
+    torch.cuda.synchronize()
+    h = a.copy()
+    gpu.negacyclic_mul_inplace(h, h)
+    assert np.array_equal(h, d.cpu().numpy().view(np.uint64))
+    assert np.array_equal(h[:n], composition(ref, q, a[:n], a[:n], n))
     big = torch.zeros(3 * n, dtype=torch.int64, device="cuda")
     with pytest.raises(amd.Panic):
         gpu.negacyclic_mul_inplace(big[:2 * n], big[n:])     # partial overlap

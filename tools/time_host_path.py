@@ -21,3 +21,14 @@ for batch in (1, 16, 32, 64, 256, 1024, 4096):
     dt = (time.perf_counter() - t0) / reps
     print("batch %5d: %.2f ms per fwd+inv of the batch -> %.0f pairs/s, %.1f GB/s over PCIe each way"
           % (batch, dt * 1e3, batch / dt, 2 * batch * n * 8 / dt / 1e9))
+
+# negacyclic products from and to pageable memory (a <- a * b; b is only read)
+for batch in (64, 1024):
+    a = rng.integers(0, q, batch * n, dtype=np.uint64)
+    b = rng.integers(0, q, batch * n, dtype=np.uint64)
+    t.negacyclic_mul_inplace(a, b)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        t.negacyclic_mul_inplace(a, b)
+    dt = (time.perf_counter() - t0) / 3
+    print("batch %5d: %.2f ms per batch of products -> %.0f products/s" % (batch, dt * 1e3, batch / dt))
