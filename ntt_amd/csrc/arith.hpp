@@ -111,6 +111,23 @@ NTTX_HD uint32_t mulhi32(uint32_t a, uint32_t b)
     return (uint32_t)(((uint64_t)a * b) >> 32);
 #endif
 }
+// a - b on 64-bit values as exactly two instructions (hipcc sometimes regroups a subtraction whose
+// operands were assembled from halves into five).
+NTTX_HD uint64_t sub64(uint64_t a, uint64_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+    uint32_t rl, rh;
+    asm("v_sub_co_u32 %0, vcc, %2, %4\n\t"
+        "s_nop 1\n\t"
+        "v_subb_co_u32 %1, vcc, %3, %5, vcc"
+        : "=&v"(rl), "=&v"(rh)
+        : "v"((uint32_t)a), "v"((uint32_t)(a >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32))
+        : "vcc");
+    return ((uint64_t)rh << 32) | rl;
+#else
+    return a - b;
+#endif
+}
 NTTX_HD uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 NTTX_HD uint32_t lo32(uint64_t x) { return (uint32_t)x; }
 NTTX_HD uint32_t hi32(uint64_t x) { return (uint32_t)(x >> 32); }
@@ -216,7 +233,7 @@ struct Shoup61 {
         const uint64_t sum = mul_add(u, b, s, c);  // u + v, v in [0, 4q)
         const uint64_t t = (u << 1) + c.q4;
         a = sum;                                   // [0, 8q)
-        b = t - sum;                               // u - v + 4q in (0, 8q)
+        b = sub64(t, sum);                         // u - v + 4q in (0, 8q)
     }
 
     // Gentleman-Sande, values in [0, 4q) in and out (ntt.rs:200-221 on lazy residues).
