@@ -47,6 +47,12 @@ def main():
     ap.add_argument("--kernel-reps", type=int, default=10, help="event-timed launches per kernel for the roofline")
     args = ap.parse_args()
 
+    # stdout carries the JSON line and nothing else: libraries that write to file descriptor 1
+    # (RCCL prints a version banner there when its first communicator comes up) go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -68,7 +74,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -234,7 +240,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
