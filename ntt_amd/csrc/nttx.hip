@@ -877,6 +877,15 @@ int run_device(const nttx_plan* plan, int device, void* dptr, size_t batch, void
     return rc;
 }
 
+// Fills the regrouped copy of a twiddle table on the device that holds the table itself.
+template <class E>
+__global__ void regroup_kernel(const E* __restrict__ src, E* __restrict__ dst, uint64_t n, uint32_t logn)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        dst[nttx::permuted_index(i, logn)] = src[i];
+}
+
 int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
 {
     int count = 0;
@@ -905,13 +914,6 @@ int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
                                 : plain ? (const char*)plan->h_fwd_plain.data() : (const char*)plan->h_fwd.data();
     const char* src_inv = pairs ? (const char*)plan->h_inv2.data()
                                 : plain ? (const char*)plan->h_inv_plain.data() : (const char*)plan->h_inv.data();
-    // regrouped copies for the pass that holds the last four stages
-    std::vector<char> perm_fwd(bytes), perm_inv(bytes);
-    for (uint64_t i = 0; i < plan->n; i++) {
-        const uint64_t j = nttx::permuted_index(i, plan->logn);
-        std::memcpy(&perm_fwd[j * esz], src_fwd + i * esz, esz);
-        std::memcpy(&perm_inv[j * esz], src_inv + i * esz, esz);
-    }
     const size_t nd = plan->devices.size();
     plan->host_slots.clear();
     for (size_t i = 0; i < nd; i++)
@@ -928,8 +930,24 @@ int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
         HIP_TRY(hipMalloc(&plan->d_inv_perm[i], bytes));
         HIP_TRY(hipMemcpy(plan->d_fwd[i], src_fwd, bytes, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(plan->d_inv[i], src_inv, bytes, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(plan->d_fwd_perm[i], perm_fwd.data(), bytes, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(plan->d_inv_perm[i], perm_inv.data(), bytes, hipMemcpyHostToDevice));
+        // regrouped copies for the pass that holds the last four stages, made on the device
+        const unsigned grid = (unsigned)((plan->n + 255) / 256);
+        (void)hipGetLastError();
+        if (pairs) {
+            using E = nttx::TwPair;
+            hipLaunchKernelGGL(regroup_kernel<E>, dim3(grid), dim3(256), 0, nullptr, static_cast<const E*>(plan->d_fwd[i]),
+                               static_cast<E*>(plan->d_fwd_perm[i]), plan->n, plan->logn);
+            hipLaunchKernelGGL(regroup_kernel<E>, dim3(grid), dim3(256), 0, nullptr, static_cast<const E*>(plan->d_inv[i]),
+                               static_cast<E*>(plan->d_inv_perm[i]), plan->n, plan->logn);
+        } else {
+            using E = uint64_t;
+            hipLaunchKernelGGL(regroup_kernel<E>, dim3(grid), dim3(256), 0, nullptr, static_cast<const E*>(plan->d_fwd[i]),
+                               static_cast<E*>(plan->d_fwd_perm[i]), plan->n, plan->logn);
+            hipLaunchKernelGGL(regroup_kernel<E>, dim3(grid), dim3(256), 0, nullptr, static_cast<const E*>(plan->d_inv[i]),
+                               static_cast<E*>(plan->d_inv_perm[i]), plan->n, plan->logn);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
     }
     (void)hipSetDevice(prev);
     // the derived tables now live on the devices; only the caller's tables stay for nttx_plan_tables
