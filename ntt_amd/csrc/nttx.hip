@@ -949,6 +949,20 @@ int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
     }
+    // The split transform exchanges pieces between the plan's devices: let them reach each other's
+    // memory directly over xGMI where the topology allows it (otherwise peer copies are staged).
+    for (size_t i = 0; i < nd; i++) {
+        for (size_t j = 0; j < nd; j++) {
+            int can = 0;
+            if (i == j || hipDeviceCanAccessPeer(&can, plan->devices[i], plan->devices[j]) != hipSuccess || !can)
+                continue;
+            HIP_TRY(hipSetDevice(plan->devices[i]));
+            const hipError_t e = hipDeviceEnablePeerAccess(plan->devices[j], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                return fail(NTTX_EHIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+            (void)hipGetLastError(); // "already enabled" is not an error worth keeping
+        }
+    }
     (void)hipSetDevice(prev);
     // the derived tables now live on the devices; only the caller's tables stay for nttx_plan_tables
     std::vector<nttx::TwPair>().swap(plan->h_fwd2);
