@@ -33,7 +33,116 @@ WORKLOADS = {
     "goldilocks20": ("goldilocks", 20, 256, "batch %d x N=2^20 Goldilocks fwd+inv per GPU (BASELINE configs[2])"),
     "goldilocks16": ("goldilocks", 16, 4096, "batch %d x N=2^16 Goldilocks fwd+inv per GPU"),
     "goldilocks28": ("goldilocks", 28, 1, "%d x N=2^28 Goldilocks fwd+inv on one GPU (BASELINE configs[4]'s vector, unsplit)"),
+    # ONE vector split over all ranks with one all-to-all per direction (strong scaling); needs
+    # torch.distributed.run, one rank is allowed.  --logn picks another even size for rehearsals.
+    "goldilocks28split": ("goldilocks", 28, 1, "%d x N=2^28 Goldilocks fwd+inv split over the ranks (BASELINE configs[4])"),
 }
+
+
+def run_split(args, json_fd):
+    """One transform split over the ranks: forward = first pass on this rank's column slab, one
+    all_to_all_single over RCCL, remaining passes on its contiguous slab; backward mirrors it
+    (ntt_amd.distributed.ShardedTransform over nttx_shard_phase_device)."""
+    import torch
+    import torch.distributed as dist
+
+    import ntt_amd
+    from ntt_amd.distributed import ShardedTransform
+    from ntt_amd.sharding import max_over_ranks
+
+    if "RANK" not in os.environ:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N "
+                         "--workload goldilocks28split")
+    rank, world, local_rank = (int(os.environ[k]) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init_process_group("nccl", device_id=dev)
+    logn = args.logn or 28
+    n = 1 << logn
+    table = ntt_amd.TableGoldilock.from_root(pow(7, (QGL - 1) // (2 * n), QGL), n, devices=[local_rank])
+    st = ShardedTransform(table)
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0000 + rank)
+    hi = torch.randint(0, 2**32 - 1, (st.local,), dtype=torch.int64, device=dev, generator=gen)  # < q
+    lo = torch.randint(0, 2**32, (st.local,), dtype=torch.int64, device=dev, generator=gen)
+    col = (hi << 32) | lo
+    del hi, lo
+    original = col.clone()
+
+    def barrier():
+        dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    def step(x):
+        return st.backward(st.forward(x))
+
+    col = step(col)
+    if not torch.equal(col, original):
+        raise SystemExit("round trip failure")
+    for _ in range(args.warmup):
+        col = step(col)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        col = step(col)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
+    if not torch.equal(col, original):
+        raise SystemExit("round trip failure after the timed region")
+
+    # local phases and the exchange, event-timed on this rank (rank 0 reports its own)
+    stream = torch.cuda.current_stream(dev)
+
+    def timed(fn, reps=5):
+        out = []
+        for _ in range(reps + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            fn()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            out.append(e0.elapsed_time(e1))
+        return sum(out[1:]) / reps
+
+    npass = ntt_amd._lib.lib.nttx_pass_count(table._plan)
+    scratch = torch.empty_like(col)
+    phases = [
+        {"name": "fwd phase 0 (first pass, column layout)", "launches": 1,
+         "avg_ms": timed(lambda: st.engine.phase(col, 0, 0, rank, world))},
+        {"name": "fwd phase 1 (remaining passes, block layout)", "launches": npass - 1,
+         "avg_ms": timed(lambda: st.engine.phase(col, 0, 1, rank, world))},
+        {"name": "all_to_all_single of this rank's slab", "launches": 0,
+         "avg_ms": timed(lambda: st._all_to_all(scratch, col))},
+    ]
+    dom = max(phases[:2], key=lambda p: p["avg_ms"] / p["launches"])
+    f = st.rows.bit_length() - 1
+    stages = f if dom is phases[0] else logn - f
+    alg_bytes = 16 * st.local * stages / logn          # this rank's share of 16 n bytes, by stages
+    achieved = alg_bytes / (dom["avg_ms"] * 1e-3) / 1e9
+    value = args.steps / elapsed
+    if rank == 0:
+        out = {
+            "metric": "single N=2^%d fwd+inv NTTs/sec per node; %% of HBM roofline" % logn,
+            "value": round(value, 2), "unit": "fwd+inv NTT pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.workload][3] % 1 if logn == 28 else "1 x N=2^%d Goldilocks, split" % logn,
+                       "n": n, "modulus": hex(QGL), "shards": world, "rows_per_peer": st.rows_per_peer,
+                       "sharding": "column slabs, one all-to-all per direction, contiguous slabs"},
+            "hbm_roofline_frac": round(value * 32 * n / (world * HBM_PEAK_GBS * 1e9), 4),
+            "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes / dom["launches"],
+                         "avg_launch_ms": round(dom["avg_ms"] / dom["launches"], 4),
+                         "kernels": [{"name": p["name"], "avg_ms": round(p["avg_ms"], 4)} for p in phases]},
+            "cpu_baseline": None,
+        }
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    dist.destroy_process_group()
 
 
 def main():
@@ -45,6 +154,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="transforms per GPU (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=10, help="event-timed launches per kernel for the roofline")
+    ap.add_argument("--logn", type=int, default=0, help="goldilocks28split only: another (even) log2 n for rehearsals")
     args = ap.parse_args()
 
     # stdout carries the JSON line and nothing else: libraries that write to file descriptor 1
@@ -52,6 +162,9 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+
+    if args.workload == "goldilocks28split":
+        return run_split(args, json_fd)
 
     import numpy as np
     import torch

@@ -86,13 +86,33 @@ class ShardedTransform:
         self.local, self.rows, self.cols, self.rows_per_peer = self.engine.geometry(self.world)
         self._device_collective = dist.get_backend(group) == "nccl"
 
+    # Elements per collective call.  RCCL 2.26 (torch 2.10 + ROCm 7) silently leaves the tail of a
+    # 2 GiB all_to_all_single unwritten (seen with 2^28 int64 on one rank; 2^27 is intact), so larger
+    # slabs go in several calls.
+    MAX_ELEMS_PER_CALL = 1 << 27
+
     def _all_to_all(self, recv, send):
-        if self._device_collective or not send.is_cuda:
-            self.dist.all_to_all_single(recv, send, group=self.group)
-        else:  # several ranks on one GPU (tests): the pieces travel through host memory
+        if self.world == 1:
+            recv.copy_(send)
+            return
+        if not (self._device_collective or not send.is_cuda):
+            # several ranks on one GPU (tests): the pieces travel through host memory
             h_send, h_recv = send.cpu(), recv.cpu()
             self.dist.all_to_all_single(h_recv, h_send, group=self.group)
             recv.copy_(h_recv)
+            return
+        if send.numel() <= self.MAX_ELEMS_PER_CALL:
+            self.dist.all_to_all_single(recv, send, group=self.group)
+            return
+        g = self.world
+        piece = send.numel() // g                      # elements per peer
+        step = max(1, self.MAX_ELEMS_PER_CALL // g)
+        s2, r2 = send.view(g, piece), recv.view(g, piece)
+        for p0 in range(0, piece, step):               # the same slice of every peer's piece per call
+            part = s2[:, p0:p0 + step].contiguous()
+            got = part.new_empty(part.shape)
+            self.dist.all_to_all_single(got.view(-1), part.view(-1), group=self.group)
+            r2[:, p0:p0 + step] = got
 
     def _check_buf(self, x):
         if x.numel() != self.local:

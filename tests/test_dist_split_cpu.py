@@ -87,12 +87,15 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, logn, out_dir):
+def _worker(rank, world, port, logn, out_dir, max_elems_per_call=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import _oracle as orc
     from ntt_amd.distributed import ShardedTransform, column_slab
+
+    if max_elems_per_call:   # force the exchange into several collective calls
+        ShardedTransform.MAX_ELEMS_PER_CALL = max_elems_per_call
 
     n = 1 << logn
     psi = pow(PSI32_2_17, (1 << 16) // n, Q32)
@@ -107,8 +110,9 @@ def _worker(rank, world, port, logn, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,logn", [(2, 14), (2, 16), (4, 14), (4, 16)])
-def test_split_transform_matches_oracle(tmp_path, world, logn):
+@pytest.mark.parametrize("world,logn,max_elems_per_call", [(2, 14, 0), (2, 16, 0), (4, 14, 0), (4, 16, 0),
+                                                          (2, 14, 1024), (4, 16, 1000)])
+def test_split_transform_matches_oracle(tmp_path, world, logn, max_elems_per_call):
     import _oracle as orc
     from ntt_amd.distributed import column_slab, split_geometry
 
@@ -117,7 +121,7 @@ def test_split_transform_matches_oracle(tmp_path, world, logn):
     x = orc.splitmix_residues(Q32, n, 77)
     want = x.copy()
     orc.Table.from_prime_and_root(Q32, psi, n).forward_inplace(want)
-    mp.spawn(_worker, args=(world, _free_port(), logn, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), logn, str(tmp_path), max_elems_per_call), nprocs=world, join=True)
     local, rows, cols, rpp = split_geometry(n, world)
     assert local * world == n and rows * cols * world == n and rpp * world == rows
     for r in range(world):
