@@ -117,10 +117,13 @@ class Table<uint64_t> : public DFT<uint64_t> {
     using DFT<uint64_t>::backward_inplace;
     using DFT<uint64_t>::backward_inplace_lazy;
 
-    // ntt.rs:90-120
-    static Table from_prime_and_root(uint64_t modulus, uint64_t root, uint64_t n, const std::vector<int>& devices = {})
+    // ntt.rs:90-120.  exact_k (not in the reference): k = q^-1 mod 2^64 for every odd modulus, where
+    // MontgomeryTransformer::from_modulus (utils.rs:148-152) derives a wrong k for about half of them
+    // (12289, 65537 ...) and the library rejects the plan.
+    static Table from_prime_and_root(uint64_t modulus, uint64_t root, uint64_t n, const std::vector<int>& devices = {},
+                                     bool exact_k = false)
     {
-        host::MontgomeryTables t = host::build_montgomery_tables(modulus, root, n);
+        host::MontgomeryTables t = host::build_montgomery_tables(modulus, root, n, exact_k);
         Table out;
         out.q = modulus;
         out.psi = root;

@@ -124,6 +124,34 @@ static void panics()
     CHECK(threw);
 }
 
+// A modulus for which the reference derives a wrong k (utils.rs:148-152): rejected as the reference's
+// result would be wrong, accepted with the exact k, and then correct against plain arithmetic.
+static void exact_k_modulus()
+{
+    const uint64_t q = 12289, n = 1024;
+    const uint64_t psi = ntt::utils::mod_exp_u64(11, (q - 1) / (2 * n), q);
+    bool threw = false;
+    try {
+        Table<uint64_t>::from_prime_and_root(q, psi, n);
+    } catch (const ntt::Panic&) {
+        threw = true;
+    }
+    CHECK(threw);
+    auto t = Table<uint64_t>::from_prime_and_root(q, psi, n, {}, true);
+    std::vector<uint64_t> a(n, 0);
+    a[1] = 1; // X: its transform is psi^(2 brev(i) + 1) at output i
+    t.forward_inplace(a);
+    bool ok = true;
+    for (uint64_t i = 0; i < n; i++)
+        ok = ok && a[i] == ntt::utils::mod_exp_u64(psi, 2 * ntt::utils::bit_reverse(i, 10) + 1, q);
+    CHECK(ok);
+    auto b = random_below(q, n, 9), b0 = b;
+    t.forward_inplace(b);
+    CHECK(b != b0);
+    t.backward_inplace(b);
+    CHECK(b == b0);
+}
+
 // One transform computed by several shards must equal the unsplit transform (all three tables).
 static void split_equals_unsplit()
 {
@@ -193,6 +221,7 @@ static void negacyclic_product()
 int main()
 {
     utils_tests();
+    exact_k_modulus();
     negacyclic_product();
     split_equals_unsplit();
     base_version();
