@@ -136,7 +136,8 @@ int nttx_negacyclic_mul_device(const nttx_plan *plan, int device, void *a, void 
 
 /*
  * Profiling hooks (no counterpart in the reference).  One forward or backward call issues
- * nttx_pass_count() kernel launches ("passes"); dir = 0 forward, 1 backward, and pass indices
+ * nttx_pass_count() kernel launches ("passes"; transforms of 2^10 and 2^12 elements run their two
+ * passes fused in one launch, except through nttx_run_pass_device and the split transform); dir = 0 forward, 1 backward, and pass indices
  * follow execution order for that direction.  nttx_pass_describe writes a short name such as
  * "fwd strided 4+4 stages 1-8" into buf.  nttx_run_pass_device enqueues ONE pass alone so a
  * benchmark can bracket it with events on its own stream; run out of sequence it leaves

@@ -636,11 +636,15 @@ __host__ __device__ inline uint64_t permuted_index(uint64_t idx, uint32_t logn)
 constexpr int TW_SET_STRIDE = 17;
 constexpr int LDSTW_ELEMS = 16 * TW_SET_STRIDE + 16;
 
-template <class A, bool FWD, bool CONTIG, bool XB>
+// FUSED (plain CONTIG tiles only): the round that talks to HBM directly (round A) reads from /
+// writes to the tile held in LDS instead, at the element's position in the tile (the CONTIG
+// exchange layout is the tile itself); fused_small_kernel runs the remaining stages around it.
+template <class A, bool FWD, bool CONTIG, bool XB, bool FUSED = false>
 __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8, XB>& g, const typename A::Ctx& c,
                                        uint64_t* lds, typename A::TwElem* ldstw)
 {
     static_assert(CONTIG || !XB, "cross-batch tiles are CONTIG tiles");
+    static_assert(!FUSED || (CONTIG && !XB), "only plain CONTIG tiles are fused");
     constexpr bool SHARED_B = !CONTIG || XB; // round B reads shared sets, round A the single set
     using RA = Round<A, CONTIG, 4, 4, true, XB>;
     using RB = Round<A, CONTIG, 4, 4, false, XB>;
@@ -692,7 +696,10 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8, XB
     };
 
     if (FWD) {
-        ra.load_global(x, p, g, c);
+        if (FUSED)
+            ra.load_lds(x, lds);
+        else
+            ra.load_global(x, p, g, c);
         stage_twiddles();
         __syncthreads();
         if (math_a)
@@ -755,7 +762,10 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8, XB
         ra.load_lds(x, lds);
         if (math_a)
             radix<A, 4, false>(x, LdsTw<A>{set_a, c}, c, scale);
-        ra.store_global(x, p, g);
+        if (FUSED)
+            ra.store_lds(x, lds); // the positions this thread just read
+        else
+            ra.store_global(x, p, g);
     }
 }
 
@@ -807,6 +817,73 @@ __global__ __launch_bounds__(THREADS, 4) void pass_kernel(PassParams p, typename
             do_round<A, FWD, CONTIG, K1, K2, false, true, false>(p, g, c, lds);
             __syncthreads();
             do_round<A, FWD, CONTIG, K1, K2, true, false, true>(p, g, c, lds);
+        }
+    }
+}
+
+// Transforms of 2^10 and 2^12 elements (KF = log2 n - 8 = 2 or 4) in ONE launch: a tile of 4096
+// contiguous elements holds whole transforms, so the KF stages with the large strides and the
+// eight-stage CONTIG pass meet in LDS instead of HBM (one round trip instead of two).  `p`
+// describes the eight-stage pass (s0 = KF, blocks of 256) with the flags of the whole transform.
+//   forward:  HBM -> KF stages in registers -> LDS (tile order) -> pass_8 -> HBM
+//   backward: HBM -> pass_8 -> LDS (tile order) -> KF stages (with the n^-1 factor) -> HBM
+template <class A, bool FWD, int KF>
+__global__ __launch_bounds__(THREADS, 4) void fused_small_kernel(PassParams p, typename A::Ctx c)
+{
+    static_assert(KF == 2 || KF == 4, "n = 2^10 or 2^12");
+    __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) typename A::TwElem ldstw[LDSTW_ELEMS];
+    using R = Round<A, false, KF, 0, true>;
+    const uint64_t tile = blockIdx.x;
+    const uint32_t outer_only = PASS_CONDITION_INPUT | PASS_POINTWISE | PASS_FINISH; // belong to the eight-stage side ...
+    PassParams pf = p; // ... except input conditioning, which is the first round's job going forward
+    pf.logB = p.logB + KF;
+    pf.s0 = 0;
+    pf.nblocks_total = p.nblocks_total >> KF;
+    pf.flags = (p.flags & ~outer_only) | (FWD ? (p.flags & PASS_CONDITION_INPUT) : 0u);
+    PassParams p8 = p;
+    p8.flags = p.flags & ~(PASS_SCALE | (FWD ? (uint32_t)PASS_CONDITION_INPUT : 0u));
+    const TileGeom<KF> gf(pf, tile);
+    const TileGeom<8> g8(p8, tile);
+    const typename A::TwElem* tw = static_cast<const typename A::TwElem*>(p.tw);
+    // position of element r of sub-transform sigma in the tile, padded as the CONTIG layout pads
+    auto at = [&](const R& r, int i) -> uint32_t {
+        const uint32_t f = (uint32_t)gf.lane_index(r.sigma, r.r0 + i);
+        return f + (f >> 4);
+    };
+    const bool math = !(p.flags & PASS_DEBUG_NO_MATH);
+
+    if (FWD) {
+#pragma unroll
+        for (int gamma = 0; gamma < R::GROUPS; gamma++) {
+            const R r(gf, gamma);
+            typename A::Tw w[R::M];
+            uint64_t x[R::M];
+            load_twiddles<A, KF>(w, tw, r.P, c);
+            r.load_global(x, pf, gf, c);
+            if (math)
+                radix<A, KF, true>(x, RegTw<A, KF>{w}, c, false);
+#pragma unroll
+            for (int i = 0; i < R::M; i++)
+                lds[at(r, i)] = x[i];
+        }
+        __syncthreads();
+        pass_8<A, true, true, false, true>(p8, g8, c, lds, ldstw);
+    } else {
+        pass_8<A, false, true, false, true>(p8, g8, c, lds, ldstw);
+        __syncthreads();
+#pragma unroll 1
+        for (int gamma = 0; gamma < R::GROUPS; gamma++) {
+            const R r(gf, gamma);
+            typename A::Tw w[R::M];
+            uint64_t x[R::M];
+            load_twiddles<A, KF>(w, tw, r.P, c);
+#pragma unroll
+            for (int i = 0; i < R::M; i++)
+                x[i] = lds[at(r, i)];
+            if (math)
+                radix<A, KF, false>(x, RegTw<A, KF>{w}, c, p.flags & PASS_SCALE);
+            r.store_global(x, pf, gf);
         }
     }
 }

@@ -336,6 +336,63 @@ int launch_pass(const nttx_plan* plan, int slot, const PassDesc& d, PassParams p
     return NTTX_OK;
 }
 
+template <class A>
+hipError_t launch_fused_policy(bool fwd, int kf, const PassParams& p, const typename A::Ctx& c, unsigned grid, hipStream_t s)
+{
+    (void)hipGetLastError();
+    if (fwd && kf == 2)
+        hipLaunchKernelGGL((fused_small_kernel<A, true, 2>), dim3(grid), dim3(THREADS), 0, s, p, c);
+    else if (fwd)
+        hipLaunchKernelGGL((fused_small_kernel<A, true, 4>), dim3(grid), dim3(THREADS), 0, s, p, c);
+    else if (kf == 2)
+        hipLaunchKernelGGL((fused_small_kernel<A, false, 2>), dim3(grid), dim3(THREADS), 0, s, p, c);
+    else
+        hipLaunchKernelGGL((fused_small_kernel<A, false, 4>), dim3(grid), dim3(THREADS), 0, s, p, c);
+    return hipGetLastError();
+}
+
+// n = 2^10 or 2^12: the whole transform of `batch` vectors in one launch (fused_small_kernel).
+// `mul_with`: multiply by that batch element by element first (backward transform of a product).
+int launch_fused(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream,
+                 const uint64_t* mul_with)
+{
+    const int kf = (int)plan->logn - 8;
+    const uint64_t tiles = (((uint64_t)batch << plan->logn) + TILE - 1) / TILE;
+    if (tiles == 0 || tiles > 0x7fffffffull)
+        return fail(NTTX_EINVAL, "element count is out of range for one launch");
+    PassParams p{};
+    p.data = dptr;
+    p.data2 = mul_with;
+    p.tw = fwd ? plan->d_fwd[slot] : plan->d_inv[slot];
+    p.tw_perm = fwd ? plan->d_fwd_perm[slot] : plan->d_inv_perm[slot];
+    p.nblocks_total = (uint64_t)batch << kf;
+    p.block_base = 0;
+    p.logB = 8;
+    p.s0 = (uint32_t)kf;
+    p.flags = PASS_CONDITION_INPUT | PASS_OFFSET32 | (fwd ? (uint32_t)PASS_FINISH : (uint32_t)PASS_SCALE) |
+              (mul_with ? (uint32_t)PASS_POINTWISE : 0u);
+    const bool product = mul_with != nullptr;
+    hipError_t e;
+    switch (plan->policy) {
+    case nttx_plan::GOLDILOCKS: e = launch_fused_policy<Goldilocks>(fwd, kf, p, plan->gctx, (unsigned)tiles, stream); break;
+    case nttx_plan::GOLDILOCKS_CANONICAL:
+        e = launch_fused_policy<GoldilocksCanonical>(fwd, kf, p, plan->gctx, (unsigned)tiles, stream);
+        break;
+    case nttx_plan::MONT_WIDE:
+        e = launch_fused_policy<Mont<true>>(fwd, kf, p, product ? plan->mctx_mul : plan->mctx, (unsigned)tiles, stream);
+        break;
+    case nttx_plan::MONT:
+        e = launch_fused_policy<Mont<false>>(fwd, kf, p, product ? plan->mctx_mul : plan->mctx, (unsigned)tiles, stream);
+        break;
+    default:
+        e = launch_fused_policy<Shoup61>(fwd, kf, p, product ? plan->sctx_mul : plan->sctx, (unsigned)tiles, stream);
+        break;
+    }
+    if (e != hipSuccess)
+        return fail(NTTX_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return NTTX_OK;
+}
+
 // Flags of the pass at forward-order position `fi` of `np` when running direction `fwd`.
 uint32_t pass_flags(const PassDesc& d, size_t fi, size_t np, bool fwd)
 {
@@ -358,7 +415,10 @@ int enqueue_passes(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch
                    int only_pass, const uint64_t* mul_with = nullptr)
 {
     static const bool no_xb = std::getenv("NTTX_NO_CROSS_BATCH") != nullptr;
+    static const bool no_fused = std::getenv("NTTX_NO_FUSED_SMALL") != nullptr;
     const size_t np = plan->passes.size();
+    if ((plan->logn == 10 || plan->logn == 12) && only_pass < 0 && !no_fused)
+        return launch_fused(plan, slot, dptr, batch, fwd, stream, mul_with);
     for (size_t i = 0; i < np; i++) {
         if (only_pass >= 0 && (size_t)only_pass != i)
             continue;

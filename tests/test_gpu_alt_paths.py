@@ -4,6 +4,8 @@ once per process -- so each variant runs the pass-shape parity tests in a child 
   NTTX_NO_BUFFER_ADDRESSING  64-bit global addressing, the path of blocks above 2^28 elements
   NTTX_NO_CROSS_BATCH        plain contiguous tiles for every batch (otherwise only batch mod 16)
   NTTX_NO_HOST_STAGING       host batches of any size copied straight from the caller's memory
+  NTTX_NO_FUSED_SMALL        n = 2^10 and 2^12 as two launches (otherwise only split transforms and
+                             the profiling entry point run them so)
 """
 import os
 import subprocess
@@ -17,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SELECT = "all_pass_shapes or montgomery_table or device_resident_batch or large_host or any_u64 or lazily"
 
 
-@pytest.mark.parametrize("switches", [("NTTX_NO_BUFFER_ADDRESSING",), ("NTTX_NO_CROSS_BATCH", "NTTX_NO_HOST_STAGING")])
+@pytest.mark.parametrize("switches", [("NTTX_NO_BUFFER_ADDRESSING",), ("NTTX_NO_CROSS_BATCH", "NTTX_NO_HOST_STAGING", "NTTX_NO_FUSED_SMALL")])
 def test_parity_on_alternative_paths(switches):
     env = dict(os.environ)
     for s in switches:
