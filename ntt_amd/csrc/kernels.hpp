@@ -737,9 +737,9 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8, XB
     } else {
         if (CONTIG) {
             typename A::Tw w[16];
-            if (!SHARED_B && twl)
-                load_last(w);
             copy_contig<A, 8, true, XB>(p, g, c, lds);
+            if (!SHARED_B && twl)
+                load_last(w); // after the tile copy: 64 more live registers during it would spill
             stage_twiddles();
             __syncthreads();
             rb.load_lds(x, lds);
