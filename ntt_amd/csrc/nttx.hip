@@ -810,10 +810,9 @@ int run_host_on(const nttx_plan* plan, size_t i, uint64_t* data, size_t count, b
     static const bool no_staging = std::getenv("NTTX_NO_HOST_STAGING") != nullptr;
     if (!no_staging && vec_bytes >= STAGE_MIN_BYTES &&
         (sizeof(uint64_t) << plan->logn) <= (other ? STAGE_CHUNK_BYTES / 2 : STAGE_CHUNK_BYTES)) {
-        int rc = ensure_staging(s);
-        if (rc != NTTX_OK)
-            return rc;
-        return run_staged(plan, (int)i, s, data, count, fwd, other);
+        if (ensure_staging(s) == NTTX_OK)
+            return run_staged(plan, (int)i, s, data, count, fwd, other);
+        (void)hipGetLastError(); // no pinned memory to be had: the plain path below still works
     }
     uint64_t* d = nullptr;
     bool own = false; // d was allocated for this call (too large to keep)
