@@ -1,9 +1,9 @@
 """Randomised parity sweep on a GPU box (not part of the test suite): random table kinds, sizes,
 batches and inputs -- residues, arbitrary u64 and edge values -- through the host entry points,
 the split transform and the negacyclic product, each compared with the CPU oracle.
-Usage: python tools/fuzz_parity.py [seconds] [seed]"""
+Usage: python tests/manual/fuzz_parity.py [seconds] [seed]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
