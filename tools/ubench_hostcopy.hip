@@ -2,7 +2,7 @@
 //   (a) hipMemcpy from/to pageable memory (what the runtime does by itself),
 //   (b) hipHostRegister in place, async copies, hipHostUnregister,
 //   (c) staging through two pinned buffers filled by host threads, copies overlapped.
-// Build: hipcc -O3 --offload-arch=gfx950 tools/ubench_hostcopy.hip -o gpurun_out/ubench_hostcopy -lpthread
+// Build: hipcc -O3 --offload-arch=gfx950 tools/ubench_hostcopy.hip -o tools/ubench_hostcopy -lpthread
 #include <hip/hip_runtime.h>
 
 #include <chrono>
