@@ -136,10 +136,10 @@ int nttx_negacyclic_mul_device(const nttx_plan *plan, int device, void *a, void 
 
 /*
  * Profiling hooks (no counterpart in the reference).  One forward or backward call issues
- * nttx_pass_count() kernel launches ("passes"; transforms of 2^10 and 2^12 elements run their two
- * passes fused in one launch, except through nttx_run_pass_device and the split transform); dir = 0 forward, 1 backward, and pass indices
+ * nttx_pass_count() kernel launches ("passes"); dir = 0 forward, 1 backward, and pass indices
  * follow execution order for that direction.  nttx_pass_describe writes a short name such as
- * "fwd strided 4+4 stages 1-8" into buf.  nttx_run_pass_device enqueues ONE pass alone so a
+ * "fwd strided 4+4 stages 1-8" into buf ("fwd fused 4+8 stages 9-20": the launch that runs the
+ * last 8 + 2 or 8 + 4 stages when log2 n is 2 or 4 mod 8).  nttx_run_pass_device enqueues ONE pass alone so a
  * benchmark can bracket it with events on its own stream; run out of sequence it leaves
  * meaningless data in dptr, so it is for timing only.
  */
@@ -152,9 +152,9 @@ int nttx_run_pass_device(const nttx_plan *plan, int device, void *dptr, size_t b
  * ONE transform of n elements split over n_shards = 2^k shards (a single vector too large or
  * too slow for one GPU; the reference runs any length in one loop nest, ntt.rs:122-176 and
  * :178-236, ntt_goldilock.rs:81-180 -- these calls compute the same result).  The split
- * follows the reference's index structure: the first f butterfly stages (f = stage count of the
- * first pass, nttx_pass_describe(plan, 0, 0)) only couple elements whose indices agree modulo
- * n/2^f, and after them the vector is 2^f independent contiguous blocks.
+ * follows the reference's index structure: the first f butterfly stages (f = log2 n mod 8, or 8
+ * when that is 0; nttx_shard_geometry reports rows = 2^f) only couple elements whose indices
+ * agree modulo n/2^f, and after them the vector is 2^f independent contiguous blocks.
  *
  *   column layout of shard d: a [rows = 2^f][cols = n/(2^f * n_shards)] array holding, of every
  *     row of n/2^f consecutive elements of the vector, the columns [d*cols, (d+1)*cols).

@@ -821,10 +821,11 @@ __global__ __launch_bounds__(THREADS, 4) void pass_kernel(PassParams p, typename
     }
 }
 
-// Transforms of 2^10 and 2^12 elements (KF = log2 n - 8 = 2 or 4) in ONE launch: a tile of 4096
-// contiguous elements holds whole transforms, so the KF stages with the large strides and the
-// eight-stage CONTIG pass meet in LDS instead of HBM (one round trip instead of two).  `p`
-// describes the eight-stage pass (s0 = KF, blocks of 256) with the flags of the whole transform.
+// The last 8 + KF stages (KF = 2 or 4) in ONE launch: a tile of 4096 contiguous elements holds
+// whole blocks of 2^(8 + KF) elements, so the KF stages with strides 128..1024 and the eight-stage
+// CONTIG pass meet in LDS instead of HBM (one round trip fewer).  Transforms of 2^10 and 2^12
+// elements are done completely this way; longer ones with log2 n = 2 or 4 mod 8 end with it.  `p`
+// describes the eight-stage pass (s0 = log2 n - 8, blocks of 256) with the flags of both parts.
 //   forward:  HBM -> KF stages in registers -> LDS (tile order) -> pass_8 -> HBM
 //   backward: HBM -> pass_8 -> LDS (tile order) -> KF stages (with the n^-1 factor) -> HBM
 template <class A, bool FWD, int KF>
@@ -838,8 +839,9 @@ __global__ __launch_bounds__(THREADS, 4) void fused_small_kernel(PassParams p, t
     const uint32_t outer_only = PASS_CONDITION_INPUT | PASS_POINTWISE | PASS_FINISH; // belong to the eight-stage side ...
     PassParams pf = p; // ... except input conditioning, which is the first round's job going forward
     pf.logB = p.logB + KF;
-    pf.s0 = 0;
+    pf.s0 = p.s0 - KF;
     pf.nblocks_total = p.nblocks_total >> KF;
+    pf.block_base = p.block_base >> KF;
     pf.flags = (p.flags & ~outer_only) | (FWD ? (p.flags & PASS_CONDITION_INPUT) : 0u);
     PassParams p8 = p;
     p8.flags = p.flags & ~(PASS_SCALE | (FWD ? (uint32_t)PASS_CONDITION_INPUT : 0u));

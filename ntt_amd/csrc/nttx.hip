@@ -61,6 +61,7 @@ struct PassDesc {
     int k1, k2;
     bool contig;
     uint32_t s0;
+    int fused = 0; // 2 or 4: the stages s0 - fused + 1 .. s0 run in the same launch (fused_small_kernel)
 };
 
 // Host threads that move a caller's pageable slice to and from pinned staging memory.  One
@@ -173,7 +174,8 @@ struct nttx_plan {
     std::vector<int> devices;
     std::vector<void*> d_fwd, d_inv;           // per device: tables in the reference's index order
     std::vector<void*> d_fwd_perm, d_inv_perm; // per device: last four stages regrouped (permuted_index)
-    std::vector<PassDesc> passes;        // forward order
+    std::vector<PassDesc> passes;        // launches of a batched transform, forward order
+    std::vector<PassDesc> split_passes;  // launches of a split transform: never fused, first pass = log2 n mod 8 (or 8) stages
     // Host-slice calls (nttx_*_host) keep one stream and one staging buffer per device between
     // calls, so a single-vector call pays two copies and the kernels, not an allocation.
     struct HostSlot {
@@ -228,6 +230,23 @@ std::vector<PassDesc> make_passes(uint32_t logn)
         out.push_back(d);
         s0 += 8;
     }
+    return out;
+}
+
+// Launches of a batched transform.  When log2 n = 2 or 4 mod 8 the short first pass of
+// make_passes is dropped: 8-stage STRIDED passes from stage 1 on, and the last 8 + (log2 n mod 8)
+// stages in one fused launch -- one HBM round trip fewer (NTTX_NO_FUSED_SMALL keeps make_passes).
+std::vector<PassDesc> make_schedule(uint32_t logn)
+{
+    const uint32_t kf = logn % 8;
+    if ((kf != 2 && kf != 4) || logn < 10 || std::getenv("NTTX_NO_FUSED_SMALL") != nullptr)
+        return make_passes(logn);
+    std::vector<PassDesc> out;
+    for (uint32_t s0 = 0; s0 + 8 + kf < logn; s0 += 8)
+        out.push_back(PassDesc{4, 4, false, s0});
+    PassDesc tail{4, 4, true, logn - 8};
+    tail.fused = (int)kf;
+    out.push_back(tail);
     return out;
 }
 
@@ -351,12 +370,14 @@ hipError_t launch_fused_policy(bool fwd, int kf, const PassParams& p, const type
     return hipGetLastError();
 }
 
-// n = 2^10 or 2^12: the whole transform of `batch` vectors in one launch (fused_small_kernel).
+// The last 8 + kf stages of `batch` vectors (kf = log2 n mod 8 = 2 or 4) in one launch
+// (fused_small_kernel); for n = 2^10 and 2^12 that is the whole transform.
 // `mul_with`: multiply by that batch element by element first (backward transform of a product).
 int launch_fused(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream,
                  const uint64_t* mul_with)
 {
-    const int kf = (int)plan->logn - 8;
+    const int kf = (int)(plan->logn % 8);
+    const bool whole = plan->logn == (uint32_t)(8 + kf); // no stage precedes (forward) / follows (backward) this launch
     const uint64_t tiles = (((uint64_t)batch << plan->logn) + TILE - 1) / TILE;
     if (tiles == 0 || tiles > 0x7fffffffull)
         return fail(NTTX_EINVAL, "element count is out of range for one launch");
@@ -365,12 +386,15 @@ int launch_fused(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, 
     p.data2 = mul_with;
     p.tw = fwd ? plan->d_fwd[slot] : plan->d_inv[slot];
     p.tw_perm = fwd ? plan->d_fwd_perm[slot] : plan->d_inv_perm[slot];
-    p.nblocks_total = (uint64_t)batch << kf;
+    p.nblocks_total = (uint64_t)batch << (plan->logn - 8);
     p.block_base = 0;
     p.logB = 8;
-    p.s0 = (uint32_t)kf;
-    p.flags = PASS_CONDITION_INPUT | PASS_OFFSET32 | (fwd ? (uint32_t)PASS_FINISH : (uint32_t)PASS_SCALE) |
-              (mul_with ? (uint32_t)PASS_POINTWISE : 0u);
+    p.s0 = plan->logn - 8;
+    p.flags = PASS_OFFSET32 | (mul_with ? (uint32_t)PASS_POINTWISE : 0u);
+    if (fwd)
+        p.flags |= PASS_FINISH | (whole ? (uint32_t)PASS_CONDITION_INPUT : 0u);
+    else
+        p.flags |= PASS_CONDITION_INPUT | (whole ? (uint32_t)PASS_SCALE : 0u);
     const bool product = mul_with != nullptr;
     hipError_t e;
     switch (plan->policy) {
@@ -415,15 +439,18 @@ int enqueue_passes(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch
                    int only_pass, const uint64_t* mul_with = nullptr)
 {
     static const bool no_xb = std::getenv("NTTX_NO_CROSS_BATCH") != nullptr;
-    static const bool no_fused = std::getenv("NTTX_NO_FUSED_SMALL") != nullptr;
     const size_t np = plan->passes.size();
-    if ((plan->logn == 10 || plan->logn == 12) && only_pass < 0 && !no_fused)
-        return launch_fused(plan, slot, dptr, batch, fwd, stream, mul_with);
     for (size_t i = 0; i < np; i++) {
         if (only_pass >= 0 && (size_t)only_pass != i)
             continue;
         const size_t fi = fwd ? i : np - 1 - i;
         const PassDesc& d = plan->passes[fi];
+        if (d.fused) { // sets its own flags: it is the last forward / first backward launch
+            int rc = launch_fused(plan, slot, dptr, batch, fwd, stream, fwd ? nullptr : mul_with);
+            if (rc != NTTX_OK)
+                return rc;
+            continue;
+        }
         const bool xb_shape = d.contig && d.k1 == 4 && d.k2 == 4 && !no_xb;
         const size_t xb_batch = xb_shape ? batch & ~(size_t)15 : 0;
         for (int part = 0; part < 2; part++) {
@@ -480,10 +507,10 @@ int shard_geometry(const nttx_plan* plan, int n_shards, ShardGeom& g)
         return fail(NTTX_EINVAL, "plan is NULL");
     if (n_shards < 1 || n_shards > 64 || (n_shards & (n_shards - 1)) != 0)
         return fail(NTTX_EINVAL, "number of shards must be a power of two in [1, 64]");
-    if (plan->passes.size() < 2)
+    if (plan->split_passes.size() < 2)
         return fail(NTTX_EINVAL, "n is too small to split (needs n >= 2^10)");
     g.k = ntt::host::ilog2((uint64_t)n_shards);
-    g.f = (uint32_t)(plan->passes[0].k1 + plan->passes[0].k2);
+    g.f = (uint32_t)(plan->split_passes[0].k1 + plan->split_passes[0].k2);
     if (g.f < g.k)
         return fail(NTTX_EINVAL, "too many shards for this n: the first pass has fewer stages than log2(shards)");
     if (plan->logn < g.f + g.k + 4 || plan->logn < g.k + TILE_LOG)
@@ -500,11 +527,11 @@ int shard_geometry(const nttx_plan* plan, int n_shards, ShardGeom& g)
 int enqueue_shard_phase(const nttx_plan* plan, int slot, uint64_t* dptr, bool fwd, int phase, int shard,
                         const ShardGeom& g, hipStream_t stream)
 {
-    const size_t np = plan->passes.size();
+    const size_t np = plan->split_passes.size();
     const uint64_t tiles = g.local / TILE;
     for (size_t i = 0; i < np; i++) {
         const size_t fi = fwd ? i : np - 1 - i;
-        const PassDesc& d = plan->passes[fi];
+        const PassDesc& d = plan->split_passes[fi];
         if ((phase == 0) != (fi == 0))
             continue;
         PassParams p{};
@@ -1124,7 +1151,8 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
         delete plan;
         return fail(NTTX_ENOMEM, "out of host memory");
     }
-    plan->passes = make_passes(logn);
+    plan->passes = make_schedule(logn);
+    plan->split_passes = make_passes(logn);
     int rc = guarded([&] { return finish_plan(plan, devices, n_devices); });
     if (rc != NTTX_OK) {
         std::string keep = g_err;
@@ -1310,8 +1338,12 @@ int nttx_pass_describe(const nttx_plan* plan, int dir, int pass_index, char* buf
     if (pass_index < 0 || pass_index >= np || (dir != 0 && dir != 1))
         return fail(NTTX_EINVAL, "pass index or direction out of range");
     const PassDesc& d = plan->passes[dir == 0 ? pass_index : np - 1 - pass_index];
-    std::snprintf(buf, buf_len, "%s %s %d+%d stages %u-%u", dir == 0 ? "fwd" : "bwd", d.contig ? "contig" : "strided",
-                  d.k1, d.k2, d.s0 + 1, d.s0 + (unsigned)(d.k1 + d.k2));
+    if (d.fused)
+        std::snprintf(buf, buf_len, "%s fused %d+8 stages %u-%u", dir == 0 ? "fwd" : "bwd", d.fused, d.s0 - d.fused + 1,
+                      d.s0 + 8);
+    else
+        std::snprintf(buf, buf_len, "%s %s %d+%d stages %u-%u", dir == 0 ? "fwd" : "bwd", d.contig ? "contig" : "strided",
+                      d.k1, d.k2, d.s0 + 1, d.s0 + (unsigned)(d.k1 + d.k2));
     return NTTX_OK;
 }
 

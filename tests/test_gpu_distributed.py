@@ -149,6 +149,10 @@ def test_two_to_the_28_goldilocks(amd):
     t3 = time.time()
     assert np.array_equal(split, want), "GPU transform differs from the oracle"
     del want
+    back = split.copy()
+    gpu.backward_inplace(back)   # unsplit: three launches, the last stages fused
+    assert np.array_equal(back, x), "unsplit round trip"
+    del back
     gpu.backward_inplace_distributed(split, 8)
     assert np.array_equal(split, x), "round trip"
     print("2^28: plan %.1fs, gpu %.1fs, oracle %.1fs, backward %.1fs" % (t1 - t0, t2 - t1, t3 - t2, time.time() - t3))

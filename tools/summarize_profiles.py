@@ -13,6 +13,9 @@ shutil.copy(src + "/bench.json", "profiles/%s_bench.json" % tag)
 
 
 def short(name):
+    m = re.search(r"fused_small_kernel<nttx::(\w+(?:<\w+>)?), (\w+), (\d)>", name)
+    if m:  # bench.py calls it "fwd fused 4+8 stages ..."
+        return (m.group(1), "fwd" if m.group(2) == "true" else "bwd", "fused", int(m.group(3)), 8)
     m = re.search(r"pass_kernel<nttx::(\w+(?:<\w+>)?), (\w+), (\w+), (\d), (\d)(?:, (\w+))?>", name)
     if not m:
         return None
