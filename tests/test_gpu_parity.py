@@ -94,6 +94,20 @@ def test_goldilocks_prime_through_montgomery_table(amd, logn):
     _batch_check(gpu, ref, QGL, n, 3, 3000 + logn)
 
 
+def test_two_to_the_26_goldilocks(amd):
+    """log2 n = 2 mod 8 above 2^18: two 8-stage passes, then the last 10 stages in one launch."""
+    n = 1 << 26
+    psi = psigl_for(n)
+    gpu, ref = amd.TableGoldilock.from_root(psi, n), orc.TableGoldilock.from_root(psi, n)
+    x = orc.splitmix_residues(QGL, n, 26)
+    a, w = x.copy(), x.copy()
+    gpu.forward_inplace(a)
+    ref.forward_inplace(w)
+    assert np.array_equal(a, w), "forward"
+    gpu.backward_inplace(a)
+    assert np.array_equal(a, x), "round trip"
+
+
 def test_base_version(amd):  # dft.rs:23-42
     table = amd.Table.new_goldilock()
     a = orc.splitmix_residues(table.q, 1 << 16, 11)
