@@ -138,6 +138,40 @@ struct alignas(16) TwPair {
     uint64_t v;
 };
 
+// 64-bit add as ONE instruction (v_lshl_add_u64).  A carry chain (v_add_co_u32 + v_addc_co_u32) costs
+// about three times as much on gfx950: two instructions that cannot issue back to back.
+NTTX_HD uint64_t add64(uint64_t a, uint64_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+    uint64_t d;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+#else
+    return a + b;
+#endif
+}
+// Same with a wave-uniform second term (plan constants live in scalar registers).
+NTTX_HD uint64_t add64u(uint64_t a, uint64_t b_uniform)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+    uint64_t d;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(a), "s"(b_uniform));
+    return d;
+#else
+    return a + b_uniform;
+#endif
+}
+// 2a + b, b wave-uniform
+NTTX_HD uint64_t dbl_add64u(uint64_t a, uint64_t b_uniform)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+    uint64_t d;
+    asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(d) : "v"(a), "s"(b_uniform));
+    return d;
+#else
+    return (a << 1) + b_uniform;
+#endif
+}
 // ---------------------------------------------------------------------------------------------
 // Shoup61: q < 2^61 (so 8q <= 2^64).
 //
@@ -147,16 +181,48 @@ struct alignas(16) TwPair {
 // in [0, 4q) and is congruent to y*w.  Outputs of both reference paths are canonical residues
 // (ntt.rs:173-175, ntt_avx2.rs:276-278), so any exact arithmetic mod q that ends in a canonical
 // value reproduces them.
+//
+// Instruction costs on gfx950 (tools/ubench_issue.hip, cycles per wave instruction at four waves
+// per SIMD): v_add/sub/and/or/xor/not/mov/lshrrev/ashrrev on 32 bits about 2.5; everything else
+// (multiplies, v_lshl_add_u64, carry-out adds, v_cndmask, three-operand forms) 4.3 to 4.7.  There is
+// no cheap multiply, so what can be trimmed is the glue around the nine or ten of a product.
+//
+// NEAR = true: moduli just below 2^61 (c8 = 2^61 - q < 2^29, e.g. 0x1fffffffffe00001).  Multiples of q
+// are then a power of two minus a small constant, so "subtract k*q, k = the top bits of x" is
+// (x with those bits cleared) + k * const: three instructions, two of them full rate.
 struct Shoup61Ctx {
     uint64_t q, q2, q4;
     uint64_t nq;   // 2^64 - q
+    uint32_t c8;   // NEAR: 2^61 - q
+    uint32_t pad_;
     TwPair one;    // (1, floor(2^64 / q)): reduces an arbitrary u64 input
     TwPair scale;  // n^-1 (plain residue) and its quotient
     TwPair scale1; // tw[1] * n^-1 mod q and its quotient (twiddle of inverse stage 1, pre-scaled)
     uint64_t k;    // q^-1 mod 2^64 (utils.rs:130), for the product of two data words
 };
 
-struct Shoup61 {
+// True when the NEAR forms apply to q.
+NTTX_HD bool shoup61_is_near(uint64_t q) { return q < (1ull << 61) && (1ull << 61) - q < (1ull << 29); }
+
+// Plan constants from the modulus, n^-1, the (plain) twiddle of inverse stage 1 times n^-1, and k.
+inline Shoup61Ctx make_shoup61_ctx(uint64_t q, uint64_t n_inv_plain, uint64_t s1_plain, uint64_t k)
+{
+    auto pair_of = [&](uint64_t w) { return TwPair{w, (uint64_t)((((unsigned __int128)w) << 64) / q)}; };
+    Shoup61Ctx c{};
+    c.q = q;
+    c.q2 = 2 * q;
+    c.q4 = 4 * q;
+    c.nq = 0 - q;
+    c.c8 = shoup61_is_near(q) ? (uint32_t)((1ull << 61) - q) : 0u;
+    c.one = pair_of(1 % q);
+    c.scale = pair_of(n_inv_plain);
+    c.scale1 = pair_of(s1_plain);
+    c.k = k;
+    return c;
+}
+
+template <bool NEAR>
+struct Shoup61T {
     using Ctx = Shoup61Ctx;
     using TwElem = TwPair;
     static constexpr bool CONDITIONS_INPUT = true;
@@ -204,7 +270,8 @@ struct Shoup61 {
     // x in [0, 2m) -> [0, m); m is a plan constant (wave-uniform).  On the device the borrow of
     // the subtraction drives the select directly: 4 instructions instead of the 5 hipcc emits
     // (it adds a separate 64-bit compare).  The s_nop's are the wait states gfx950 needs between
-    // a VALU write of VCC and a VALU read of it as carry-in / select mask.
+    // a VALU write of VCC and a VALU read of it as carry-in / select mask.  (A carry-free form --
+    // add 2^64 - m, spread the sign, mask m, add -- is five instructions and measured 6 % slower.)
     static NTTX_HD uint64_t csub(uint64_t x, uint64_t m)
     {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
@@ -225,34 +292,63 @@ struct Shoup61 {
 #endif
     }
 
-    // Cooley-Tukey, values in [0, 8q) in and out (ntt.rs:146-166 on lazy residues):
-    // a' = u + v, b' = u - v + 4q = (2u + 4q) - a' with u = a mod-ish 4q, v = b*s lazily.
-    static NTTX_HD void ct(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
+    // NEAR forms.  x - k * (2^B - e) = (x with the bits from B up cleared) + k * e for k = x >> B.
+    // fold63: k * 4q, k <= 1.  [0, 2^64) -> [0, 2^63 + 4 c8)
+    static NTTX_HD uint64_t fold63(uint64_t x, const Ctx& c)
     {
-        const uint64_t u = csub(a, c.q4);          // [0, 4q)
-        const uint64_t sum = mul_add(u, b, s, c);  // u + v, v in [0, 4q)
-        const uint64_t t = (u << 1) + c.q4;
-        a = sum;                                   // [0, 8q)
-        b = sub64(t, sum);                         // u - v + 4q in (0, 8q)
+        return mad32u(hi32(x) >> 31, c.c8 << 2, x & 0x7fffffffffffffffull);
+    }
+    // fold62: k * 2q, k <= 3.  [0, 2^64) -> [0, 2^62 + 6 c8)
+    static NTTX_HD uint64_t fold62(uint64_t x, const Ctx& c)
+    {
+        return mad32u(hi32(x) >> 30, c.c8 << 1, x & 0x3fffffffffffffffull);
+    }
+    // fold61: k * q, k <= 7.  [0, 2^64) -> [0, 2^61 + 7 c8), which lies below 2q
+    static NTTX_HD uint64_t fold61(uint64_t x, const Ctx& c)
+    {
+        return mad32u(hi32(x) >> 29, c.c8, x & 0x1fffffffffffffffull);
     }
 
-    // Gentleman-Sande, values in [0, 4q) in and out (ntt.rs:200-221 on lazy residues).
+    // Cooley-Tukey (ntt.rs:146-166 on lazy residues): a' = u + v, b' = u - v + 4q with u = a less a
+    // multiple of 4q and v = b*s lazily in [0, 4q).
+    //   general: values in [0, 8q); u = a - 4q when a >= 4q.
+    //   NEAR:    values in [0, 2^64); u = a - 4q when a >= 2^63, so u < 2^63 + 4 c8 = 2^64 - 4q and
+    //            u + v < 2^64.  2u + 4q may wrap; b' itself lies in (0, 2^64), so the wrap cancels.
+    static NTTX_HD void ct(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
+    {
+        const uint64_t u = NEAR ? fold63(a, c) : csub(a, c.q4);
+        const uint64_t sum = mul_add(u, b, s, c);
+        const uint64_t t = dbl_add64u(u, c.q4);
+        a = sum;
+        b = sub64(t, sum);                          // 2u + 4q - (u + v)
+    }
+
+    // Gentleman-Sande (ntt.rs:200-221 on lazy residues), values in [0, 4q) in and out: a' = u + v
+    // less a multiple of q, b' = (u - v + 4q) * s lazily.
+    //   general: a' = u + v - 4q when that is not negative.
+    //   NEAR:    a' = u + v - k * 2q, k = (u + v) >> 62: below 2^62 + 6 c8 < 4q.
     static NTTX_HD void gs(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c)
     {
         const uint64_t u = a, v = b;
-        a = csub(u + v, c.q4);                     // [0, 4q)
-        b = mul((u + c.q4) - v, s, c);             // input (0, 8q) -> [0, 4q)
+        const uint64_t sum = add64(u, v);
+        a = NEAR ? fold62(sum, c) : csub(sum, c.q4);
+        b = mul(sub64(add64u(u, c.q4), v), s, c);          // input (0, 8q) -> [0, 4q)
     }
 
     // [0, 4q) -> [0, q)
-    static NTTX_HD uint64_t canon4(uint64_t x, const Ctx& c) { return csub(csub(x, c.q2), c.q); }
+    static NTTX_HD uint64_t canon4(uint64_t x, const Ctx& c)
+    {
+        if (NEAR)
+            return csub(fold61(x, c), c.q);
+        return csub(csub(x, c.q2), c.q);
+    }
 
     // Stage 1 of the inverse with the n^-1 factor of ntt.rs:231-235 folded in; canonical outputs.
     static NTTX_HD void gs_last(uint64_t& a, uint64_t& b, const Tw&, const Ctx& c)
     {
         const uint64_t u = a, v = b;
-        a = canon4(mul(u + v, make(c.scale), c), c);
-        b = canon4(mul((u + c.q4) - v, make(c.scale1), c), c);
+        a = canon4(mul(add64(u, v), make(c.scale), c), c);
+        b = canon4(mul(sub64(add64u(u, c.q4), v), make(c.scale1), c), c);
     }
 
     // ntt.rs:125-127, 181-183: the reference's first sweep maps any u64 to its residue.
@@ -272,9 +368,17 @@ struct Shoup61 {
         return (hi < mq_hi) ? r + c.q : r;
     }
 
-    // [0, 8q) -> [0, q): the canonical value ntt.rs:173-175 ends with.
-    static NTTX_HD uint64_t finish(uint64_t x, const Ctx& c) { return canon4(csub(x, c.q4), c); }
+    // End of the forward transform: the canonical value ntt.rs:173-175 ends with.
+    //   general: [0, 8q) -> [0, q);  NEAR: [0, 2^64) -> [0, q)
+    static NTTX_HD uint64_t finish(uint64_t x, const Ctx& c)
+    {
+        if (NEAR)
+            return csub(fold61(x, c), c.q);
+        return canon4(csub(x, c.q4), c);
+    }
 };
+using Shoup61 = Shoup61T<false>;
+using Shoup61Near = Shoup61T<true>;
 
 // ---------------------------------------------------------------------------------------------
 // Strict 64-bit Montgomery on canonical residues.  `k` is q^-1 mod 2^64 as the reference's

@@ -16,7 +16,7 @@
 
 #include "../../include/nttx.h"
 #include "../host/tables.hpp"
-#include "kernels.hpp"
+#include "launch.hpp"
 
 namespace {
 
@@ -56,13 +56,6 @@ int guarded(F&& body) noexcept
         }
     }
 }
-
-struct PassDesc {
-    int k1, k2;
-    bool contig;
-    uint32_t s0;
-    int fused = 0; // 2 or 4: the stages s0 - fused + 1 .. s0 run in the same launch (fused_small_kernel)
-};
 
 // Host threads that move a caller's pageable slice to and from pinned staging memory.  One
 // memcpy stream per core is far below what a PCIe 5 x16 link carries; several in parallel keep
@@ -160,7 +153,7 @@ struct nttx_plan {
     uint64_t q = 0, k = 0, n = 0, n_inv = 0;
     uint32_t logn = 0;
     // arithmetic policy of the kernels (arith.hpp)
-    enum Policy { SHOUP61, MONT, MONT_WIDE, GOLDILOCKS, GOLDILOCKS_CANONICAL } policy = MONT;
+    enum Policy { SHOUP61, SHOUP61_NEAR, MONT, MONT_WIDE, GOLDILOCKS, GOLDILOCKS_CANONICAL } policy = MONT;
     nttx::MontCtx mctx{};
     nttx::Shoup61Ctx sctx{};
     nttx::GoldilocksCtx gctx{};
@@ -174,8 +167,8 @@ struct nttx_plan {
     std::vector<int> devices;
     std::vector<void*> d_fwd, d_inv;           // per device: tables in the reference's index order
     std::vector<void*> d_fwd_perm, d_inv_perm; // per device: last four stages regrouped (permuted_index)
-    std::vector<PassDesc> passes;        // launches of a batched transform, forward order
-    std::vector<PassDesc> split_passes;  // launches of a split transform: never fused, first pass = log2 n mod 8 (or 8) stages
+    std::vector<nttx::PassDesc> passes;        // launches of a batched transform, forward order
+    std::vector<nttx::PassDesc> split_passes;  // launches of a split transform: never fused, first pass = log2 n mod 8 (or 8) stages
     // Host-slice calls (nttx_*_host) keep one stream and one staging buffer per device between
     // calls, so a single-vector call pays two copies and the kernels, not an allocation.
     struct HostSlot {
@@ -250,45 +243,6 @@ std::vector<PassDesc> make_schedule(uint32_t logn)
     return out;
 }
 
-template <class A, bool FWD, bool CONTIG, int K1, int K2, bool XB = false>
-hipError_t launch_one(const PassParams& p, const typename A::Ctx& c, unsigned grid, hipStream_t s)
-{
-    (void)hipGetLastError(); // drop any error an earlier, unrelated call left behind on this thread
-    // NTTX_DEBUG_EXTRA_LDS=<bytes>: unused dynamic LDS per workgroup, to lower occupancy in experiments
-    static const unsigned extra_lds = [] {
-        const char* e = std::getenv("NTTX_DEBUG_EXTRA_LDS");
-        return e ? (unsigned)std::atol(e) : 0u;
-    }();
-    hipLaunchKernelGGL((pass_kernel<A, FWD, CONTIG, K1, K2, XB>), dim3(grid), dim3(THREADS), extra_lds, s, p, c);
-    return hipGetLastError();
-}
-
-template <class A, bool FWD>
-hipError_t launch_shape(const PassDesc& d, const PassParams& p, const typename A::Ctx& c, unsigned grid,
-                        hipStream_t s)
-{
-    const int key = ((p.flags & PASS_CROSS_BATCH) ? 1000 : 0) + (d.contig ? 100 : 0) + d.k1 * 10 + d.k2;
-    switch (key) {
-    case 1144: return launch_one<A, FWD, true, 4, 4, true>(p, c, grid, s);
-    case 120: return launch_one<A, FWD, true, 2, 0>(p, c, grid, s);
-    case 140: return launch_one<A, FWD, true, 4, 0>(p, c, grid, s);
-    case 142: return launch_one<A, FWD, true, 4, 2>(p, c, grid, s);
-    case 144: return launch_one<A, FWD, true, 4, 4>(p, c, grid, s);
-    case 20: return launch_one<A, FWD, false, 2, 0>(p, c, grid, s);
-    case 40: return launch_one<A, FWD, false, 4, 0>(p, c, grid, s);
-    case 42: return launch_one<A, FWD, false, 4, 2>(p, c, grid, s);
-    case 44: return launch_one<A, FWD, false, 4, 4>(p, c, grid, s);
-    default: return hipErrorInvalidValue;
-    }
-}
-
-template <class A>
-hipError_t launch_dir(bool fwd, const PassDesc& d, const PassParams& p, const typename A::Ctx& c, unsigned grid,
-                      hipStream_t s)
-{
-    return fwd ? launch_shape<A, true>(d, p, c, grid, s) : launch_shape<A, false>(d, p, c, grid, s);
-}
-
 int device_slot(const nttx_plan* plan, int device)
 {
     for (size_t i = 0; i < plan->devices.size(); i++)
@@ -342,32 +296,20 @@ int launch_pass(const nttx_plan* plan, int slot, const PassDesc& d, PassParams p
         p.flags |= PASS_DEBUG_NO_TW;
     hipError_t e;
     switch (plan->policy) {
-    case nttx_plan::GOLDILOCKS: e = launch_dir<Goldilocks>(fwd, d, p, plan->gctx, (unsigned)tiles, stream); break;
+    case nttx_plan::GOLDILOCKS: e = launch_pass_policy<Goldilocks>(fwd, d, p, plan->gctx, (unsigned)tiles, stream); break;
     case nttx_plan::GOLDILOCKS_CANONICAL:
-        e = launch_dir<GoldilocksCanonical>(fwd, d, p, plan->gctx, (unsigned)tiles, stream);
+        e = launch_pass_policy<GoldilocksCanonical>(fwd, d, p, plan->gctx, (unsigned)tiles, stream);
         break;
-    case nttx_plan::MONT_WIDE: e = launch_dir<Mont<true>>(fwd, d, p, product ? plan->mctx_mul : plan->mctx, (unsigned)tiles, stream); break;
-    case nttx_plan::MONT: e = launch_dir<Mont<false>>(fwd, d, p, product ? plan->mctx_mul : plan->mctx, (unsigned)tiles, stream); break;
-    default: e = launch_dir<Shoup61>(fwd, d, p, product ? plan->sctx_mul : plan->sctx, (unsigned)tiles, stream); break;
+    case nttx_plan::MONT_WIDE: e = launch_pass_policy<Mont<true>>(fwd, d, p, product ? plan->mctx_mul : plan->mctx, (unsigned)tiles, stream); break;
+    case nttx_plan::MONT: e = launch_pass_policy<Mont<false>>(fwd, d, p, product ? plan->mctx_mul : plan->mctx, (unsigned)tiles, stream); break;
+    case nttx_plan::SHOUP61_NEAR:
+        e = launch_pass_policy<Shoup61Near>(fwd, d, p, product ? plan->sctx_mul : plan->sctx, (unsigned)tiles, stream);
+        break;
+    default: e = launch_pass_policy<Shoup61>(fwd, d, p, product ? plan->sctx_mul : plan->sctx, (unsigned)tiles, stream); break;
     }
     if (e != hipSuccess)
         return fail(NTTX_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return NTTX_OK;
-}
-
-template <class A>
-hipError_t launch_fused_policy(bool fwd, int kf, const PassParams& p, const typename A::Ctx& c, unsigned grid, hipStream_t s)
-{
-    (void)hipGetLastError();
-    if (fwd && kf == 2)
-        hipLaunchKernelGGL((fused_small_kernel<A, true, 2>), dim3(grid), dim3(THREADS), 0, s, p, c);
-    else if (fwd)
-        hipLaunchKernelGGL((fused_small_kernel<A, true, 4>), dim3(grid), dim3(THREADS), 0, s, p, c);
-    else if (kf == 2)
-        hipLaunchKernelGGL((fused_small_kernel<A, false, 2>), dim3(grid), dim3(THREADS), 0, s, p, c);
-    else
-        hipLaunchKernelGGL((fused_small_kernel<A, false, 4>), dim3(grid), dim3(THREADS), 0, s, p, c);
-    return hipGetLastError();
 }
 
 // The last 8 + kf stages of `batch` vectors (kf = log2 n mod 8 = 2 or 4) in one launch
@@ -407,6 +349,9 @@ int launch_fused(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, 
         break;
     case nttx_plan::MONT:
         e = launch_fused_policy<Mont<false>>(fwd, kf, p, product ? plan->mctx_mul : plan->mctx, (unsigned)tiles, stream);
+        break;
+    case nttx_plan::SHOUP61_NEAR:
+        e = launch_fused_policy<Shoup61Near>(fwd, kf, p, product ? plan->sctx_mul : plan->sctx, (unsigned)tiles, stream);
         break;
     default:
         e = launch_fused_policy<Shoup61>(fwd, kf, p, product ? plan->sctx_mul : plan->sctx, (unsigned)tiles, stream);
@@ -992,7 +937,7 @@ int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
     plan->devices = devs; // only validated indices reach the plan (its destructor visits them)
     int prev = 0;
     (void)hipGetDevice(&prev);
-    const bool pairs = plan->policy == nttx_plan::SHOUP61;
+    const bool pairs = plan->policy == nttx_plan::SHOUP61 || plan->policy == nttx_plan::SHOUP61_NEAR;
     const size_t esz = pairs ? sizeof(nttx::TwPair) : sizeof(uint64_t);
     const size_t bytes = plan->n * esz;
     const bool plain = plan->policy == nttx_plan::GOLDILOCKS_CANONICAL;
@@ -1106,7 +1051,9 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
     if (kind == NTTX_GOLDILOCKS)
         plan->policy = nttx_plan::GOLDILOCKS;
     else if (q < (1ull << 61))
-        plan->policy = nttx_plan::SHOUP61; // 8q <= 2^64: lazy butterflies
+        // 8q <= 2^64: lazy butterflies; moduli just below 2^61 get the cheaper reductions (NTTX_NO_NEAR: not)
+        plan->policy = nttx::shoup61_is_near(q) && std::getenv("NTTX_NO_NEAR") == nullptr ? nttx_plan::SHOUP61_NEAR
+                                                                                           : nttx_plan::SHOUP61;
     else if (q == nttx::Goldilocks::Q)
         plan->policy = nttx_plan::GOLDILOCKS_CANONICAL; // Table::new_goldilock: the prime's own arithmetic
     else
@@ -1119,7 +1066,7 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
     try {
         plan->h_fwd.assign(psi_bo, psi_bo + n);
         plan->h_inv.assign(psi_inv_bo, psi_inv_bo + n);
-        if (plan->policy == nttx_plan::SHOUP61) {
+        if (plan->policy == nttx_plan::SHOUP61 || plan->policy == nttx_plan::SHOUP61_NEAR) {
             // The kernels multiply plain data by plain twiddles with a precomputed quotient:
             // w = REDC(w * 2^64) (utils.rs:165-178), v = floor(w * 2^64 / q).
             const ntt::utils::MontgomeryTransformer<uint64_t> mt{k, 0, q};
@@ -1132,10 +1079,9 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
             }
             const uint64_t n_inv_plain = mt.reduce((u128)n_inv);
             const uint64_t s1 = (uint64_t)(((u128)plan->h_inv2[1].w * n_inv_plain) % q);
-            plan->sctx = nttx::Shoup61Ctx{q, 2 * q, 4 * q, 0 - q, pair_of(1 % q), pair_of(n_inv_plain), pair_of(s1), k};
-            plan->sctx_mul = plan->sctx;
-            plan->sctx_mul.scale = pair_of((uint64_t)(((u128)n_inv_plain * r_mod_q) % q));
-            plan->sctx_mul.scale1 = pair_of((uint64_t)(((u128)s1 * r_mod_q) % q));
+            plan->sctx = nttx::make_shoup61_ctx(q, n_inv_plain, s1, k);
+            plan->sctx_mul = nttx::make_shoup61_ctx(q, (uint64_t)(((u128)n_inv_plain * r_mod_q) % q),
+                                                    (uint64_t)(((u128)s1 * r_mod_q) % q), k);
         }
         if (plan->policy == nttx_plan::GOLDILOCKS_CANONICAL) {
             const ntt::utils::MontgomeryTransformer<uint64_t> mt{k, 0, q};

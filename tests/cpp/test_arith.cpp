@@ -25,8 +25,59 @@ static uint64_t mulmod(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)((
 
 static Shoup61Ctx make_shoup_ctx(uint64_t q, uint64_t n_inv_plain, uint64_t s1_plain)
 {
-    auto pair_of = [&](uint64_t w) { return TwPair{w, (uint64_t)(((u128)w << 64) / q)}; };
-    return Shoup61Ctx{q, 2 * q, 4 * q, 0 - q, pair_of(1), pair_of(n_inv_plain), pair_of(s1_plain), 0};
+    return make_shoup61_ctx(q, n_inv_plain, s1_plain, 0);
+}
+
+// Single butterflies of the lazy policies on values at the edges of their documented ranges:
+// outputs stay in range (as exact integers, no wrap) and are congruent to the plain butterfly.
+template <bool NEAR>
+static void shoup_butterfly_bounds(uint64_t q)
+{
+    using A = Shoup61T<NEAR>;
+    std::mt19937_64 rng(q + NEAR);
+    Shoup61Ctx c = make_shoup_ctx(q, 1, 1);
+    const u128 two64 = (u128)1 << 64;
+    // CT takes and leaves [0, 8q) (general) or any u64 (NEAR); GS takes and leaves [0, 4q)
+    const uint64_t ct_hi = NEAR ? ~0ull : 8 * q - 1, gs_hi = 4 * q - 1;
+    auto pick = [&](uint64_t hi, int it) -> uint64_t {
+        const uint64_t e[] = {0, 1, q - 1, q, q + 1, 2 * q - 1, 2 * q, 4 * q - 1, 4 * q, 4 * q + 1, (1ull << 62) - 1,
+                              1ull << 62, (1ull << 63) - 1, 1ull << 63, (1ull << 63) + 1, hi - 1, hi};
+        uint64_t x = (it & 1) ? e[rng() % (sizeof(e) / sizeof(e[0]))] : rng();
+        if (x > hi)
+            x = hi == ~0ull ? x : x % (hi + 1);
+        return x;
+    };
+    for (int it = 0; it < 400000; it++) {
+        const uint64_t w = it < 4 ? (uint64_t[]){0, 1, q - 1, q / 2}[it] : rng() % q;
+        const typename A::Tw t = A::make(TwPair{w, (uint64_t)(((u128)w << 64) / q)});
+        {
+            const uint64_t a0 = pick(ct_hi, it), b0 = pick(ct_hi, it >> 1);
+            uint64_t a = a0, b = b0;
+            A::ct(a, b, t, c);
+            const uint64_t v = mulmod(b0 % q, w, q);
+            CHECK(a % q == (uint64_t)(((u128)(a0 % q) + v) % q));
+            CHECK(b % q == (uint64_t)(((u128)(a0 % q) + q - v) % q));
+            CHECK(a <= ct_hi && b <= ct_hi);
+            CHECK(A::finish(a, c) == a % q && A::finish(b, c) == b % q);
+        }
+        {
+            const uint64_t a0 = pick(gs_hi, it), b0 = pick(gs_hi, it >> 1);
+            uint64_t a = a0, b = b0;
+            A::gs(a, b, t, c);
+            CHECK(a % q == (uint64_t)(((u128)a0 + b0) % q));
+            CHECK(b % q == mulmod((uint64_t)(((u128)a0 + 4 * (u128)q - b0) % q), w, q));
+            CHECK(a <= gs_hi && b <= gs_hi);
+            CHECK(A::canon4(a, c) == a % q && A::canon4(b, c) == b % q);
+            a = a0;
+            b = b0;
+            A::gs_last(a, b, t, c);
+            CHECK(a == mulmod((uint64_t)(((u128)a0 + b0) % q), c.scale.w, q));
+            CHECK(b == mulmod((uint64_t)(((u128)a0 + 4 * (u128)q - b0) % q), c.scale1.w, q));
+        }
+        const uint64_t x = rng();
+        CHECK(A::condition_input(x, c) == x % q);
+        (void)two64;
+    }
 }
 
 static void shoup_mul_bounds(uint64_t q)
@@ -152,6 +203,13 @@ static void transform_tests(uint64_t q, uint64_t psi, size_t n)
         CHECK(a == want);
         backward<Shoup61>(a, b2, sc);
         for (size_t i = 0; i < n; i++) CHECK(a[i] == in[i] % q);
+        if (shoup61_is_near(q)) {
+            a = in;
+            forward<Shoup61Near>(a, f2, sc);
+            CHECK(a == want);
+            backward<Shoup61Near>(a, b2, sc);
+            for (size_t i = 0; i < n; i++) CHECK(a[i] == in[i] % q);
+        }
     }
 }
 
@@ -211,6 +269,13 @@ int main()
     shoup_mul_bounds(4293918721ull);
     shoup_mul_bounds((1ull << 61) - 1); // not prime; bounds and congruence hold for any odd modulus
     shoup_mul_bounds(7681);
+    shoup_butterfly_bounds<false>(q61);
+    shoup_butterfly_bounds<true>(q61);
+    shoup_butterfly_bounds<false>(4293918721ull);
+    shoup_butterfly_bounds<false>((1ull << 61) - 1);
+    shoup_butterfly_bounds<true>((1ull << 61) - 1);
+    shoup_butterfly_bounds<true>((1ull << 61) - (1ull << 29) + 1); // the smallest modulus the NEAR forms take
+    shoup_butterfly_bounds<false>(7681);
     for (size_t n : {4, 16, 256, 4096}) {
         transform_tests(q61, ntt::utils::mod_exp_u64(psi61, (1 << 16) / n, q61), n);
         transform_tests(Goldilocks::Q, ntt::utils::mod_exp_u64(0xabd0a6e8aa3d8a0eull, (1 << 16) / n, Goldilocks::Q), n);
