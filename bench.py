@@ -4,8 +4,11 @@
 One "step" = forward_inplace followed by backward_inplace (the reference's README loop,
 src/main.rs:28-31) over one device-resident batch of 4096 vectors of 2^16 residues modulo
 0x1fffffffffe00001 per GPU (BASELINE.json configs[1]).  Inputs are synthetic uniform residues
-generated on the device before the timed region.  With --gpus N (launched by torch.distributed.run,
-one rank per GPU) every rank transforms its own batch; no data-path collective exists.
+generated on the device before the timed region.  With --gpus N every rank (one process per GPU)
+transforms its own batch; no data-path collective exists.  Started without RANK in the environment
+and N > 1, this process launches the N ranks itself (torch.distributed.run as a child, before
+anything here touches a GPU) and relays rank 0's JSON line.  --total-batch B fixes the job's batch
+and splits it over the ranks instead (strong scaling).
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against HBM bandwidth
 using algorithmic bytes; `cpu_baseline` times the CPU oracle (the C restatement of the reference)
@@ -39,6 +42,75 @@ WORKLOADS = {
 }
 
 
+def launch_ranks(argv, gpus):
+    """Starts `gpus` ranks of this script under torch.distributed.run and relays their stdout (rank 0's
+    JSON line).  Runs before any GPU call in this process: a process that has initialised the GPU
+    must not be replaced, so the ranks are children and this process only waits for them."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
+
+
+def rank_device(local_rank):
+    """Device of a local rank and whether ranks share devices (more ranks than visible GPUs: a
+    rehearsal on a smaller box; RCCL refuses two ranks on one device, so those runs line ranks up
+    over gloo).  torch.cuda.device_count() does not initialise the GPU."""
+    import torch
+
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("no GPU visible")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    return local_rank % ndev, world > ndev
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def kernel_source_stamp():
+    """Hash of the kernel sources: PMC summaries under profiles/ carry the stamp of the sources they
+    were measured on, and are only quoted while it matches."""
+    import hashlib
+
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "ntt_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hpp", ".hip")):
+            with open(os.path.join(src, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_counter(kind, workload, kernel_name):
+    """profiles/<kind>_<workload>.json entry for a kernel, or None (with a warning) when the file is
+    missing, was measured on other kernel sources, or lacks the kernel."""
+    path = os.path.join(ROOT, "profiles", "%s_%s.json" % (kind, workload))
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        rec = json.load(fh)
+    if rec.get("_stamp") != kernel_source_stamp():
+        sys.stderr.write("bench.py: %s was measured on other kernel sources (stamp %s, now %s): not quoted; "
+                         "rerun tools/refresh_profiles.sh\n" % (path, rec.get("_stamp"), kernel_source_stamp()))
+        return None
+    return rec.get(kernel_name)
+
+
 def run_split(args, json_fd):
     """One transform split over the ranks: forward = first pass on this rank's column slab, one
     all_to_all_single over RCCL, remaining passes on its contiguous slab; backward mirrors it
@@ -50,15 +122,16 @@ def run_split(args, json_fd):
     from ntt_amd.distributed import ShardedTransform
     from ntt_amd.sharding import max_over_ranks
 
-    if "RANK" not in os.environ:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N "
-                         "--workload goldilocks28split")
     rank, world, local_rank = (int(os.environ[k]) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    local_rank, shared = rank_device(local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist.init_process_group("nccl", device_id=dev)
+    if shared:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)
     logn = args.logn or 28
     n = 1 << logn
     table = ntt_amd.TableGoldilock.from_root(pow(7, (QGL - 1) // (2 * n), QGL), n, devices=[local_rank])
@@ -73,7 +146,11 @@ def run_split(args, json_fd):
     original = col.clone()
 
     def barrier():
-        dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+        if shared:
+            dist.barrier()
+        else:
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     def step(x):
@@ -89,7 +166,7 @@ def run_split(args, json_fd):
     for _ in range(args.steps):
         col = step(col)
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, None if shared else dev)
     if not torch.equal(col, original):
         raise SystemExit("round trip failure after the timed region")
 
@@ -152,10 +229,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mont16")
     ap.add_argument("--batch", type=int, default=0, help="transforms per GPU (0 = the workload's default)")
+    ap.add_argument("--total-batch", type=int, default=0,
+                    help="transforms of the whole job, split contiguously over the ranks (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=10, help="event-timed launches per kernel for the roofline")
     ap.add_argument("--logn", type=int, default=0, help="goldilocks28split only: another (even) log2 n for rehearsals")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "RANK" not in os.environ and (args.gpus > 1 or args.workload == "goldilocks28split"):
+        sys.exit(launch_ranks(sys.argv[1:], args.gpus))
 
     # stdout carries the JSON line and nothing else: libraries that write to file descriptor 1
     # (RCCL prints a version banner there when its first communicator comes up) go to stderr
@@ -171,7 +254,7 @@ def main():
 
     import ntt_amd
     from ntt_amd._lib import lib
-    from ntt_amd.sharding import job_throughput, max_over_ranks
+    from ntt_amd.sharding import max_over_ranks, shard_range
 
     kind, LOGN, default_batch, describe = WORKLOADS[args.workload]
     N = 1 << LOGN
@@ -180,23 +263,36 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    local_rank, shared = rank_device(local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if shared:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
-    batch = args.batch or default_batch
+    strong = args.total_batch > 0
+    if strong:
+        if args.total_batch < world:
+            raise SystemExit("--total-batch must be at least the number of ranks")
+        batch = shard_range(args.total_batch, world, rank)[1]
+        job_batch = args.total_batch
+    else:
+        batch = args.batch or default_batch
+        job_batch = batch * world
     if kind == "mont":
         q = Q61
         table = ntt_amd.Table.from_prime_and_root(Q61, PSI61, N, devices=[local_rank])
@@ -245,11 +341,11 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, dist, dev)
+    elapsed = max_over_ranks(elapsed, dist, None if shared else dev)
     if not torch.equal(data, original):
         raise SystemExit("round trip failure after the timed region")
 
-    value = job_throughput(batch, world, args.steps, elapsed)
+    value = job_batch * args.steps / elapsed  # units all ranks processed / the slowest rank's time
     frac_job = value * 32 * N / (world * HBM_PEAK_GBS * 1e9)
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, per pass -----------
@@ -284,23 +380,18 @@ def main():
     alg_bytes = 16 * N * batch * (int(b) - int(a) + 1) / LOGN
     achieved = alg_bytes / (dom["avg_ms"] * 1e-3) / 1e9
     # HBM bytes per launch of that kernel from the PMC passes recorded under profiles/ (FETCH_SIZE
-    # doubled as the gfx950 guide prescribes, plus WRITE_SIZE), if one was taken for this workload
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-    if os.path.exists(tpath) and batch == default_batch:
-        with open(tpath) as fh:
-            traffic = json.load(fh).get(dom["name"])
-    # second bound: integer VALU.  Wave-level VALU instructions per launch of that kernel from the
-    # PMC pass recorded under profiles/ (SQ_INSTS_VALU); a wave64 instruction occupies its SIMD's
-    # 16 lanes for at least 4 cycles, and the chip has 1024 SIMDs at 2.4 GHz.
+    # doubled as the gfx950 guide prescribes, plus WRITE_SIZE), quoted only while the kernel sources
+    # are the ones they were measured on and the batch is the one they were measured at
+    at_default = batch == default_batch
+    traffic = recorded_counter("traffic", args.workload, dom["name"]) if at_default else None
+    # second bound: integer VALU.  Wave-level VALU instructions per launch of that kernel
+    # (SQ_INSTS_VALU); a wave64 instruction holds its SIMD for about 4 cycles (the multiplies and
+    # 64-bit forms that make up most of a butterfly: tools/ubench_issue.hip), 1024 SIMDs at 2.4 GHz.
     valu = None
-    vpath = os.path.join(ROOT, "profiles", "valu_%s.json" % args.workload)
-    if os.path.exists(vpath) and batch == default_batch:
-        with open(vpath) as fh:
-            insts = json.load(fh).get(dom["name"])
-        if insts:
-            valu = {"wave_instructions_per_launch": insts,
-                    "issue_utilisation": round(insts * 4 / (dom["avg_ms"] * 1e-3 * 1024 * 2.4e9), 3)}
+    insts = recorded_counter("valu", args.workload, dom["name"]) if at_default else None
+    if insts:
+        valu = {"wave_instructions_per_launch": insts,
+                "issue_utilisation": round(insts * 4 / (dom["avg_ms"] * 1e-3 * 1024 * 2.4e9), 3)}
     roofline = {
         "bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -322,9 +413,14 @@ def main():
             oracle.forward_inplace(want)
             if not np.array_equal(got, want):
                 raise SystemExit("parity failure on transform %d" % b)
-        cores = max(1, min(16, len(os.sched_getaffinity(0))))
+        # threads: every core this process may run on, unless the box sets a thread budget for jobs
+        # (OMP_NUM_THREADS on the shared GPU hosts, whose affinity mask shows the whole machine)
+        host_cores = len(os.sched_getaffinity(0))
+        budget = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+        cores = max(1, min(host_cores, budget) if budget > 0 else host_cores)
         okind = 0 if kind == "mont" else 2
-        per_thread = max(2, (150 << 16) >> LOGN if kind == "mont" else (40 << 16) >> LOGN)
+        # bounded sample: about 1.5 s of transforms per thread
+        per_thread = max(2, (600 << 16) >> LOGN if kind == "mont" else (300 << 16) >> LOGN)
         secs = orc.bench_pairs(okind, oracle, N, per_thread, cores)
         single = {}
         for k2, name, tab in ((0, "base", orc.Table.new()), (1, "avx2", orc.TableAVX2.new()),
@@ -332,7 +428,7 @@ def main():
             single[name + "_ms_30_pairs_1_thread"] = round(orc.bench_pairs(k2, tab, 1 << 16, 30, 1) * 1e3, 1)
         cpu = {
             "value": round(cores * per_thread / secs, 1), "unit": "fwd+inv NTT pairs/s", "cores": cores,
-            "kind": "port",
+            "threads": cores, "host_cores": host_cores, "cpu_model": cpu_model(), "kind": "port",
             "sample": "%d threads x %d pairs, N=2^%d, %s (C oracle)"
                       % (cores, per_thread, LOGN, "scalar Montgomery Table, q=0x1fffffffffe00001" if kind == "mont"
                          else "TableGoldilock"),
@@ -345,10 +441,12 @@ def main():
             "value": round(value, 1), "unit": "fwd+inv NTT pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": describe % batch, "batch_per_gpu": batch, "n": N, "modulus": hex(q),
-                       "sharding": "batch split, no collective"},
+            "config": {"workload": (describe % job_batch).replace("per GPU", "in the job, split over %d GPUs" % world)
+                       if strong else describe % batch, "batch_per_gpu": batch,
+                       "job_batch": job_batch, "n": N, "modulus": hex(q),
+                       "sharding": "batch split, no collective" + (", ranks share devices" if shared else "")},
             "hbm_roofline_frac": round(frac_job, 4),
             "roofline": roofline,
             "cpu_baseline": cpu,

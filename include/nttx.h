@@ -89,6 +89,13 @@ void nttx_plan_destroy(nttx_plan *plan);
 int nttx_plan_info(const nttx_plan *plan, int *kind, uint64_t *q, uint64_t *k, uint64_t *n,
                    uint64_t *n_inv, int *n_devices);
 int nttx_plan_tables(const nttx_plan *plan, uint64_t *psi_bo_out, uint64_t *psi_inv_bo_out);
+/* Name of the arithmetic the plan's kernels use (no counterpart in the reference; for tests and
+ * logs): "shoup61" / "shoup61_near" (NTTX_MONT64, q < 2^61: lazy butterflies on plain residues with
+ * precomputed quotients; "_near" for q within 2^29 of 2^61), "mont" / "mont_wide" (NTTX_MONT64,
+ * 2^61 <= q < 2^63 / q >= 2^63: strict REDC with R = 2^64 as utils.rs:165-187),
+ * "goldilocks_canonical" (NTTX_MONT64 with q = 0xffffffff00000001, Table::new_goldilock,
+ * ntt.rs:60-62), "goldilocks" (NTTX_GOLDILOCKS).  Static string; "" for a NULL plan. */
+const char *nttx_plan_policy(const nttx_plan *plan);
 
 /*
  * In-place transforms of `batch` independent length-n vectors stored back to back in HOST
@@ -118,6 +125,20 @@ int nttx_forward_device(const nttx_plan *plan, int device, void *dptr, size_t ba
 int nttx_backward_device(const nttx_plan *plan, int device, void *dptr, size_t batch, void *hip_stream);
 
 /*
+ * The same transforms with LAZY outputs: DFT::forward_inplace_lazy / backward_inplace_lazy
+ * (dft.rs:8,10), whose contract is "elements in [0, 2q)" (ntt.rs:31-35, 45-49; the reference's
+ * LAZY parameter is never read, so its lazy methods return canonical residues, which satisfy that
+ * contract too).  For NTTX_MONT64 plans with q < 2^61 the final canonicalising step is replaced by
+ * a cheaper one that leaves every output in [0, 2q), congruent to the canonical value; such outputs
+ * are valid inputs of every entry point here (inputs below 4q are taken as they are).  All other
+ * plans (q >= 2^61, NTTX_GOLDILOCKS) return exactly what the strict entry points return.
+ */
+int nttx_forward_host_lazy(const nttx_plan *plan, uint64_t *data, size_t batch);
+int nttx_backward_host_lazy(const nttx_plan *plan, uint64_t *data, size_t batch);
+int nttx_forward_device_lazy(const nttx_plan *plan, int device, void *dptr, size_t batch, void *hip_stream);
+int nttx_backward_device_lazy(const nttx_plan *plan, int device, void *dptr, size_t batch, void *hip_stream);
+
+/*
  * Negacyclic product a <- a * b in Z_q[X]/(X^n + 1) for `batch` pairs of polynomials (batch*n
  * coefficients each, natural order in and out).  No counterpart in the reference: it is the
  * composition its callers write around the transforms -- forward_inplace(a), forward_inplace(b)
@@ -128,7 +149,7 @@ int nttx_backward_device(const nttx_plan *plan, int device, void *dptr, size_t b
  * canonical even for the value q the forward transform can emit), so the result equals that
  * composition bit for bit.  Afterwards b holds its forward transform (device entry point; the
  * host entry point leaves the caller's b untouched).  Passing the same pointer as a and b
- * squares; partially overlapping operands are rejected.
+ * squares; partially overlapping operands are rejected (both entry points).
  */
 int nttx_negacyclic_mul_host(const nttx_plan *plan, uint64_t *a, const uint64_t *b, size_t batch);
 int nttx_negacyclic_mul_device(const nttx_plan *plan, int device, void *a, void *b, size_t batch,

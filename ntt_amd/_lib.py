@@ -23,6 +23,11 @@ SYMBOLS = {
     "nttx_backward_host": (C.c_int, [_vp, _vp, _sz]),
     "nttx_forward_device": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp]),
     "nttx_backward_device": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp]),
+    "nttx_plan_policy": (C.c_char_p, [_vp]),
+    "nttx_forward_host_lazy": (C.c_int, [_vp, _vp, _sz]),
+    "nttx_backward_host_lazy": (C.c_int, [_vp, _vp, _sz]),
+    "nttx_forward_device_lazy": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp]),
+    "nttx_backward_device_lazy": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp]),
     "nttx_negacyclic_mul_host": (C.c_int, [_vp, _vp, _vp, _sz]),
     "nttx_negacyclic_mul_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _sz, _vp]),
     "nttx_pass_count": (C.c_int, [_vp]),

@@ -351,6 +351,23 @@ struct Shoup61T {
         b = canon4(mul(sub64(add64u(u, c.q4), v), make(c.scale1), c), c);
     }
 
+    // Lazy outputs: the range [0, 2q) the reference documents for forward_inplace_lazy /
+    // backward_inplace_lazy (ntt.rs:31-35, 45-49) instead of the canonical residue.
+    static constexpr bool HAS_LAZY = true;
+    // [0, 4q) -> [0, 2q)
+    static NTTX_HD uint64_t lazy4(uint64_t x, const Ctx& c) { return NEAR ? fold61(x, c) : csub(x, c.q2); }
+    static NTTX_HD void gs_last_lazy(uint64_t& a, uint64_t& b, const Tw&, const Ctx& c)
+    {
+        const uint64_t u = a, v = b;
+        a = lazy4(mul(add64(u, v), make(c.scale), c), c);
+        b = lazy4(mul(sub64(add64u(u, c.q4), v), make(c.scale1), c), c);
+    }
+    // end of the forward transform, lazily: general [0, 8q) -> [0, 2q); NEAR [0, 2^64) -> [0, 2^61 + 7 c8)
+    static NTTX_HD uint64_t finish_lazy(uint64_t x, const Ctx& c)
+    {
+        return NEAR ? fold61(x, c) : csub(csub(x, c.q4), c.q2);
+    }
+
     // ntt.rs:125-127, 181-183: the reference's first sweep maps any u64 to its residue.
     static NTTX_HD uint64_t condition_input(uint64_t x, const Ctx& c)
     {
@@ -466,6 +483,11 @@ struct Mont {
     static NTTX_HD uint64_t pointwise(uint64_t a, uint64_t b, const Ctx& c) { return mul(a, b, c); }
 
     static NTTX_HD uint64_t finish(uint64_t x, const Ctx&) { return x; }
+
+    // strict residues throughout: the canonical outputs already lie in the lazy range [0, 2q)
+    static constexpr bool HAS_LAZY = false;
+    static NTTX_HD uint64_t finish_lazy(uint64_t x, const Ctx& c) { return finish(x, c); }
+    static NTTX_HD void gs_last_lazy(uint64_t& a, uint64_t& b, const Tw& s, const Ctx& c) { gs_last(a, b, s, c); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -816,6 +838,9 @@ struct Goldilocks {
 
     static NTTX_HD uint64_t condition_input(uint64_t x, const Ctx&) { return x; }
     static NTTX_HD uint64_t finish(uint64_t x, const Ctx&) { return x; }
+    // TableGoldilock's lazy methods run the same statements as its strict ones (ntt_goldilock.rs:25-29, 39-43)
+    static constexpr bool HAS_LAZY = false;
+    static NTTX_HD uint64_t finish_lazy(uint64_t x, const Ctx&) { return x; }
     // mul_reduce (ntt_goldilock.rs:183-190): canonical for any operands, q itself included
     static NTTX_HD uint64_t pointwise(uint64_t a, uint64_t b, const Ctx&) { return mul_strict(a, b); }
 };

@@ -42,8 +42,15 @@ enum : uint32_t {
     PASS_DEBUG_NO_MATH_B = 64u,
     PASS_CROSS_BATCH = 128u,   // CONTIG 8-stage pass: a tile is the same 256-element block of 16 consecutive transforms
     PASS_POINTWISE = 256u,     // first pass of a backward transform: multiply by the vector at data2 first
-    PASS_OFFSET32 = 512u       // every element of a tile lies within 2^31 bytes of the tile's first: buffer addressing
+    PASS_OFFSET32 = 512u,      // every element of a tile lies within 2^31 bytes of the tile's first: buffer addressing
+    PASS_LAZY = 1024u          // outputs of the transform in the policy's lazy range ([0, 2q)) instead of canonical
 };
+// radix()'s `scale` argument
+enum : int { SCALE_NONE = 0, SCALE_CANONICAL = 1, SCALE_LAZY = 2 };
+__device__ __forceinline__ int scale_mode(uint32_t flags)
+{
+    return (flags & PASS_SCALE) ? ((flags & PASS_LAZY) ? SCALE_LAZY : SCALE_CANONICAL) : SCALE_NONE;
+}
 
 struct PassParams {
     uint64_t* data;
@@ -97,7 +104,7 @@ struct LdsTw { // one 16-entry set staged in LDS, read where it is used
 // any of them may deviate from the strict rules; the stage is then redone strictly from its
 // inputs.  One branch per stage keeps the 2^(K-1) independent butterflies interleavable.
 template <class A, int K, bool FWD, class Src>
-__device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const Src& w, const typename A::Ctx& c, bool scale)
+__device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const Src& w, const typename A::Ctx& c, int scale)
 {
     constexpr int M = 1 << K;
     if constexpr (A::DEFERRED_CHECK) {
@@ -190,9 +197,15 @@ __device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const Src& w, const
             if (u == 1 && scale) {
                 // last stage of the inverse with the n^-1 factor folded in (ntt.rs:231-235)
                 const typename A::Tw s = w.get(1);
+                if (A::HAS_LAZY && scale == SCALE_LAZY) {
 #pragma unroll
-                for (int i = 0; i < half; i++)
-                    A::gs_last(x[i], x[i + half], s, c);
+                    for (int i = 0; i < half; i++)
+                        A::gs_last_lazy(x[i], x[i + half], s, c);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < half; i++)
+                        A::gs_last(x[i], x[i + half], s, c);
+                }
             } else {
 #pragma unroll
                 for (int b = 0; b < (1 << (u - 1)); b++) {
@@ -443,11 +456,17 @@ struct Round {
 };
 
 template <class A, int M>
-__device__ __forceinline__ void finish_all(uint64_t (&x)[M], const typename A::Ctx& c)
+__device__ __forceinline__ void finish_all(uint64_t (&x)[M], const typename A::Ctx& c, uint32_t flags)
 {
+    if (A::HAS_LAZY && flag_set(flags, PASS_LAZY)) {
 #pragma unroll
-    for (int i = 0; i < M; i++)
-        x[i] = A::finish(x[i], c);
+        for (int i = 0; i < M; i++)
+            x[i] = A::finish_lazy(x[i], c);
+    } else {
+#pragma unroll
+        for (int i = 0; i < M; i++)
+            x[i] = A::finish(x[i], c);
+    }
 }
 
 // Generic round: every group loads its twiddles, transforms and stores.  SRC_G / DST_G: read
@@ -470,9 +489,9 @@ __device__ __forceinline__ void do_round(const PassParams& p, const TileGeom<K1 
         else
             r.load_lds(x, lds);
         if (!(p.flags & PASS_DEBUG_NO_MATH))
-            radix<A, R::KR, FWD>(x, RegTw<A, R::KR>{w}, c, ROUND_A && (p.flags & PASS_SCALE));
+            radix<A, R::KR, FWD>(x, RegTw<A, R::KR>{w}, c, ROUND_A ? scale_mode(p.flags) : SCALE_NONE);
         if (FWD && LAST_OF_PASS && (p.flags & PASS_FINISH))
-            finish_all<A, R::M>(x, c);
+            finish_all<A, R::M>(x, c, p.flags);
         if (DST_G)
             r.store_global(x, p, g);
         else
@@ -654,7 +673,7 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8, XB
     const RA ra(g, 0);
     const RB rb(g, 0);
     uint64_t x[16];
-    const bool scale = p.flags & PASS_SCALE;
+    const int scale = scale_mode(p.flags);
     const bool math = !(p.flags & PASS_DEBUG_NO_MATH);
     const bool math_a = math && !(p.flags & PASS_DEBUG_NO_MATH_A), math_b = math && !(p.flags & PASS_DEBUG_NO_MATH_B);
     const bool twl = !(p.flags & PASS_DEBUG_NO_TW);
@@ -703,7 +722,7 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8, XB
         stage_twiddles();
         __syncthreads();
         if (math_a)
-            radix<A, 4, true>(x, LdsTw<A>{set_a, c}, c, false);
+            radix<A, 4, true>(x, LdsTw<A>{set_a, c}, c, SCALE_NONE);
         ra.store_lds(x, lds);
         if (CONTIG) {
             typename A::Tw w[16];
@@ -713,12 +732,12 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8, XB
             rb.load_lds(x, lds);
             if (math_b) {
                 if constexpr (SHARED_B)
-                    radix<A, 4, true>(x, LdsTw<A>{set_b, c}, c, false);
+                    radix<A, 4, true>(x, LdsTw<A>{set_b, c}, c, SCALE_NONE);
                 else
-                    radix<A, 4, true>(x, RegTw<A, 4>{w}, c, false);
+                    radix<A, 4, true>(x, RegTw<A, 4>{w}, c, SCALE_NONE);
             }
             if (p.flags & PASS_FINISH)
-                finish_all<A, 16>(x, c);
+                finish_all<A, 16>(x, c, p.flags);
             // Round B left each wave with four whole 256-element sub-transforms, so the way back
             // to HBM (16 bytes per lane) only moves data between lanes of one wave: no workgroup
             // barrier, the waves leave as they finish.
@@ -729,9 +748,9 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8, XB
             __syncthreads();
             rb.load_lds(x, lds);
             if (math_b)
-                radix<A, 4, true>(x, LdsTw<A>{set_b, c}, c, false);
+                radix<A, 4, true>(x, LdsTw<A>{set_b, c}, c, SCALE_NONE);
             if (p.flags & PASS_FINISH)
-                finish_all<A, 16>(x, c);
+                finish_all<A, 16>(x, c, p.flags);
             rb.store_global(x, p, g);
         }
     } else {
@@ -745,9 +764,9 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8, XB
             rb.load_lds(x, lds);
             if (math_b) {
                 if constexpr (SHARED_B)
-                    radix<A, 4, false>(x, LdsTw<A>{set_b, c}, c, false);
+                    radix<A, 4, false>(x, LdsTw<A>{set_b, c}, c, SCALE_NONE);
                 else
-                    radix<A, 4, false>(x, RegTw<A, 4>{w}, c, false);
+                    radix<A, 4, false>(x, RegTw<A, 4>{w}, c, SCALE_NONE);
             }
             rb.store_lds(x, lds);
         } else {
@@ -755,7 +774,7 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8, XB
             stage_twiddles();
             __syncthreads();
             if (math_b)
-                radix<A, 4, false>(x, LdsTw<A>{set_b, c}, c, false);
+                radix<A, 4, false>(x, LdsTw<A>{set_b, c}, c, SCALE_NONE);
             rb.store_lds(x, lds);
         }
         __syncthreads();
@@ -864,7 +883,7 @@ __global__ __launch_bounds__(THREADS, 4) void fused_small_kernel(PassParams p, t
             load_twiddles<A, KF>(w, tw, r.P, c);
             r.load_global(x, pf, gf, c);
             if (math)
-                radix<A, KF, true>(x, RegTw<A, KF>{w}, c, false);
+                radix<A, KF, true>(x, RegTw<A, KF>{w}, c, SCALE_NONE);
 #pragma unroll
             for (int i = 0; i < R::M; i++)
                 lds[at(r, i)] = x[i];
@@ -884,7 +903,7 @@ __global__ __launch_bounds__(THREADS, 4) void fused_small_kernel(PassParams p, t
             for (int i = 0; i < R::M; i++)
                 x[i] = lds[at(r, i)];
             if (math)
-                radix<A, KF, false>(x, RegTw<A, KF>{w}, c, p.flags & PASS_SCALE);
+                radix<A, KF, false>(x, RegTw<A, KF>{w}, c, scale_mode(p.flags));
             r.store_global(x, pf, gf);
         }
     }

@@ -316,7 +316,7 @@ int launch_pass(const nttx_plan* plan, int slot, const PassDesc& d, PassParams p
 // (fused_small_kernel); for n = 2^10 and 2^12 that is the whole transform.
 // `mul_with`: multiply by that batch element by element first (backward transform of a product).
 int launch_fused(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream,
-                 const uint64_t* mul_with)
+                 const uint64_t* mul_with, bool lazy)
 {
     const int kf = (int)(plan->logn % 8);
     const bool whole = plan->logn == (uint32_t)(8 + kf); // no stage precedes (forward) / follows (backward) this launch
@@ -332,7 +332,7 @@ int launch_fused(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, 
     p.block_base = 0;
     p.logB = 8;
     p.s0 = plan->logn - 8;
-    p.flags = PASS_OFFSET32 | (mul_with ? (uint32_t)PASS_POINTWISE : 0u);
+    p.flags = PASS_OFFSET32 | (mul_with ? (uint32_t)PASS_POINTWISE : 0u) | (lazy ? (uint32_t)PASS_LAZY : 0u);
     if (fwd)
         p.flags |= PASS_FINISH | (whole ? (uint32_t)PASS_CONDITION_INPUT : 0u);
     else
@@ -381,7 +381,7 @@ uint32_t pass_flags(const PassDesc& d, size_t fi, size_t np, bool fwd)
 // of 16 consecutive transforms, so a workgroup shares its twiddles) for the largest multiple of 16
 // transforms, and on plain contiguous tiles for the rest of the batch.
 int enqueue_passes(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream,
-                   int only_pass, const uint64_t* mul_with = nullptr)
+                   int only_pass, const uint64_t* mul_with, bool lazy)
 {
     static const bool no_xb = std::getenv("NTTX_NO_CROSS_BATCH") != nullptr;
     const size_t np = plan->passes.size();
@@ -391,7 +391,7 @@ int enqueue_passes(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch
         const size_t fi = fwd ? i : np - 1 - i;
         const PassDesc& d = plan->passes[fi];
         if (d.fused) { // sets its own flags: it is the last forward / first backward launch
-            int rc = launch_fused(plan, slot, dptr, batch, fwd, stream, fwd ? nullptr : mul_with);
+            int rc = launch_fused(plan, slot, dptr, batch, fwd, stream, fwd ? nullptr : mul_with, lazy);
             if (rc != NTTX_OK)
                 return rc;
             continue;
@@ -410,7 +410,8 @@ int enqueue_passes(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch
             p.block_base = 0;
             p.logB = plan->logn - d.s0;
             p.s0 = d.s0;
-            p.flags = pass_flags(d, fi, np, fwd) | (part == 0 ? (uint32_t)PASS_CROSS_BATCH : 0u);
+            p.flags = pass_flags(d, fi, np, fwd) | (part == 0 ? (uint32_t)PASS_CROSS_BATCH : 0u) |
+                      (lazy ? (uint32_t)PASS_LAZY : 0u);
             if (mul_with && i == 0) { // the first backward pass multiplies by the other transform first
                 p.data2 = mul_with + ((uint64_t)first << plan->logn);
                 p.flags |= PASS_POINTWISE;
@@ -633,8 +634,9 @@ size_t chunk_bytes()
 }
 
 // Enqueues one transform of `batch` vectors at dptr on the current device.
+// `lazy`: outputs in the arithmetic policy's lazy range instead of canonical residues.
 int enqueue(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream,
-            int only_pass = -1, const uint64_t* mul_with = nullptr)
+            int only_pass = -1, const uint64_t* mul_with = nullptr, bool lazy = false)
 {
     if (batch == 0)
         return NTTX_OK;
@@ -651,7 +653,7 @@ int enqueue(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool 
     for (size_t first = 0; first < batch; first += per) {
         const size_t count = std::min(per, batch - first);
         int rc = enqueue_passes(plan, slot, dptr + ((uint64_t)first << plan->logn), count, fwd, stream, only_pass,
-                                mul_with ? mul_with + ((uint64_t)first << plan->logn) : nullptr);
+                                mul_with ? mul_with + ((uint64_t)first << plan->logn) : nullptr, lazy);
         if (rc != NTTX_OK)
             return rc;
     }
@@ -722,7 +724,7 @@ int ensure_staging(nttx_plan::HostSlot& s)
 // kernels on the slot's stream, downloads on a second stream).  Buffers t mod D are reused every
 // D-th chunk; the one host wait per step (download of chunk t - D complete) frees all three.
 int run_staged(const nttx_plan* plan, int slot_index, nttx_plan::HostSlot& s, uint64_t* data, size_t count, bool fwd,
-               const uint64_t* other)
+               const uint64_t* other, bool lazy)
 {
     const size_t vec_bytes = sizeof(uint64_t) << plan->logn;
     const size_t room = other ? STAGE_CHUNK_BYTES / 2 : STAGE_CHUNK_BYTES; // a product keeps both operands in a chunk
@@ -750,7 +752,7 @@ int run_staged(const nttx_plan* plan, int slot_index, nttx_plan::HostSlot& s, ui
             uint64_t* const d = static_cast<uint64_t*>(s.dev[b]);
             HIP_TRY(hipMemcpyAsync(d, s.pin_in[b], other ? 2 * in_bytes : in_bytes, hipMemcpyHostToDevice, s.stream));
             int rc = other ? enqueue_product(plan, slot_index, d, d + (count_of(t) << plan->logn), count_of(t), s.stream)
-                           : enqueue(plan, slot_index, d, count_of(t), fwd, s.stream);
+                           : enqueue(plan, slot_index, d, count_of(t), fwd, s.stream, -1, nullptr, lazy);
             if (rc != NTTX_OK)
                 return rc;
             HIP_TRY(hipEventRecord(s.computed[b], s.stream));
@@ -770,7 +772,8 @@ int run_staged(const nttx_plan* plan, int slot_index, nttx_plan::HostSlot& s, ui
 
 // One device's share of a host-slice call: `count` vectors at `data` (and at `other` for a
 // negacyclic product data <- data * other; fwd is ignored then).
-int run_host_on(const nttx_plan* plan, size_t i, uint64_t* data, size_t count, bool fwd, const uint64_t* other)
+int run_host_on(const nttx_plan* plan, size_t i, uint64_t* data, size_t count, bool fwd, const uint64_t* other,
+                bool lazy)
 {
     const size_t vec_bytes = (count << plan->logn) * sizeof(uint64_t);
     const size_t bytes = other ? 2 * vec_bytes : vec_bytes;
@@ -783,7 +786,7 @@ int run_host_on(const nttx_plan* plan, size_t i, uint64_t* data, size_t count, b
     if (!no_staging && vec_bytes >= STAGE_MIN_BYTES &&
         (sizeof(uint64_t) << plan->logn) <= (other ? STAGE_CHUNK_BYTES / 2 : STAGE_CHUNK_BYTES)) {
         if (ensure_staging(s) == NTTX_OK)
-            return run_staged(plan, (int)i, s, data, count, fwd, other);
+            return run_staged(plan, (int)i, s, data, count, fwd, other, lazy);
         (void)hipGetLastError(); // no pinned memory to be had: the plain path below still works
     }
     uint64_t* d = nullptr;
@@ -810,7 +813,7 @@ int run_host_on(const nttx_plan* plan, size_t i, uint64_t* data, size_t count, b
             HIP_TRY(hipMemcpyAsync(d2, other, vec_bytes, hipMemcpyHostToDevice, s.stream));
             r = enqueue_product(plan, (int)i, d, d2, count, s.stream);
         } else {
-            r = enqueue(plan, (int)i, d, count, fwd, s.stream);
+            r = enqueue(plan, (int)i, d, count, fwd, s.stream, -1, nullptr, lazy);
         }
         if (r != NTTX_OK)
             return r;
@@ -829,7 +832,8 @@ int run_host_on(const nttx_plan* plan, size_t i, uint64_t* data, size_t count, b
 // `other` != NULL: negacyclic product data <- data * other instead of a transform (fwd ignored).
 // The batch is split evenly over the plan's devices; with several devices each share runs on a
 // host thread of its own.
-int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd, const uint64_t* other = nullptr)
+int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd, const uint64_t* other = nullptr,
+             bool lazy = false)
 {
     if (!plan)
         return fail(NTTX_EINVAL, "plan is NULL");
@@ -846,7 +850,7 @@ int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd, cons
     (void)hipGetDevice(&prev);
     int rc = NTTX_OK;
     if (ndev == 1 || batch <= per) {
-        rc = run_host_on(plan, 0, data, batch, fwd, other);
+        rc = run_host_on(plan, 0, data, batch, fwd, other, lazy);
     } else {
         std::vector<int> rcs(ndev, NTTX_OK);
         std::vector<std::string> msgs(ndev);
@@ -857,7 +861,7 @@ int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd, cons
                 const size_t first = i * per, count = std::min(per, batch - first);
                 if (i + 1 == ndev || (i + 1) * per >= batch) { // the last share runs on this thread
                     rcs[i] = run_host_on(plan, i, data + (first << plan->logn), count, fwd,
-                                         other ? other + (first << plan->logn) : nullptr);
+                                         other ? other + (first << plan->logn) : nullptr, lazy);
                     if (rcs[i] != NTTX_OK)
                         msgs[i] = g_err;
                     break;
@@ -865,7 +869,7 @@ int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd, cons
                 threads.emplace_back([&, i, first, count] {
                     rcs[i] = guarded([&] {
                         return run_host_on(plan, i, data + (first << plan->logn), count, fwd,
-                                           other ? other + (first << plan->logn) : nullptr);
+                                           other ? other + (first << plan->logn) : nullptr, lazy);
                     });
                     if (rcs[i] != NTTX_OK)
                         msgs[i] = g_err; // thread-local: carried back to the caller's thread below
@@ -887,7 +891,7 @@ int run_host(const nttx_plan* plan, uint64_t* data, size_t batch, bool fwd, cons
 }
 
 int run_device(const nttx_plan* plan, int device, void* dptr, size_t batch, void* stream, bool fwd,
-               int only_pass = -1)
+               int only_pass = -1, bool lazy = false)
 {
     if (!plan)
         return fail(NTTX_EINVAL, "plan is NULL");
@@ -902,7 +906,8 @@ int run_device(const nttx_plan* plan, int device, void* dptr, size_t batch, void
     HIP_TRY(hipGetDevice(&cur));
     if (cur != device)
         HIP_TRY(hipSetDevice(device));
-    int rc = enqueue(plan, slot, static_cast<uint64_t*>(dptr), batch, fwd, static_cast<hipStream_t>(stream), only_pass);
+    int rc = enqueue(plan, slot, static_cast<uint64_t*>(dptr), batch, fwd, static_cast<hipStream_t>(stream), only_pass,
+                     nullptr, lazy);
     if (cur != device && cur >= 0)
         (void)hipSetDevice(cur);
     return rc;
@@ -1239,10 +1244,49 @@ int nttx_backward_device(const nttx_plan* plan, int device, void* dptr, size_t b
     return run_device(plan, device, dptr, batch, hip_stream, false);
 }
 
+int nttx_forward_host_lazy(const nttx_plan* plan, uint64_t* data, size_t batch)
+{
+    return guarded([&] { return run_host(plan, data, batch, true, nullptr, true); });
+}
+int nttx_backward_host_lazy(const nttx_plan* plan, uint64_t* data, size_t batch)
+{
+    return guarded([&] { return run_host(plan, data, batch, false, nullptr, true); });
+}
+int nttx_forward_device_lazy(const nttx_plan* plan, int device, void* dptr, size_t batch, void* hip_stream)
+{
+    return run_device(plan, device, dptr, batch, hip_stream, true, -1, true);
+}
+int nttx_backward_device_lazy(const nttx_plan* plan, int device, void* dptr, size_t batch, void* hip_stream)
+{
+    return run_device(plan, device, dptr, batch, hip_stream, false, -1, true);
+}
+
+const char* nttx_plan_policy(const nttx_plan* plan)
+{
+    if (!plan)
+        return "";
+    switch (plan->policy) {
+    case nttx_plan::SHOUP61: return "shoup61";
+    case nttx_plan::SHOUP61_NEAR: return "shoup61_near";
+    case nttx_plan::MONT: return "mont";
+    case nttx_plan::MONT_WIDE: return "mont_wide";
+    case nttx_plan::GOLDILOCKS: return "goldilocks";
+    case nttx_plan::GOLDILOCKS_CANONICAL: return "goldilocks_canonical";
+    }
+    return "";
+}
+
 int nttx_negacyclic_mul_host(const nttx_plan* plan, uint64_t* a, const uint64_t* b, size_t batch)
 {
     if (batch != 0 && !b)
         return fail(NTTX_EINVAL, "second operand is NULL");
+    if (plan && batch != 0 && a) {
+        // as for the device entry point: the same pointer squares, partial overlap is refused (chunks
+        // of b are read from the caller's memory after earlier chunks of a have been written back)
+        const uint64_t total = (uint64_t)batch << plan->logn;
+        if (a != b && a < b + total && b < a + total)
+            return fail(NTTX_EINVAL, "operands overlap (pass the same pointer twice to square)");
+    }
     return guarded([&] { return run_host(plan, a, batch, true, batch ? b : nullptr); });
 }
 

@@ -84,9 +84,18 @@ class _PlanTable(DFT):
                                   C.byref(nd)))
         return dict(kind=kind.value, q=q.value, k=k.value, n=n.value, n_inv=n_inv.value, n_devices=nd.value)
 
-    def _run(self, x, forward):
-        host_fn = lib.nttx_forward_host if forward else lib.nttx_backward_host
-        dev_fn = lib.nttx_forward_device if forward else lib.nttx_backward_device
+    @property
+    def policy(self):
+        """Name of the arithmetic the plan's kernels use (nttx_plan_policy)."""
+        return lib.nttx_plan_policy(self._plan).decode()
+
+    def _run(self, x, forward, lazy=False):
+        if lazy:
+            host_fn = lib.nttx_forward_host_lazy if forward else lib.nttx_backward_host_lazy
+            dev_fn = lib.nttx_forward_device_lazy if forward else lib.nttx_backward_device_lazy
+        else:
+            host_fn = lib.nttx_forward_host if forward else lib.nttx_backward_host
+            dev_fn = lib.nttx_forward_device if forward else lib.nttx_backward_device
         if isinstance(x, np.ndarray):
             if x.dtype != self._np_dtype or not x.flags.c_contiguous or not x.flags.writeable:
                 raise TypeError("expected a writable C-contiguous %s array" % np.dtype(self._np_dtype).name)
@@ -115,15 +124,20 @@ class _PlanTable(DFT):
     def backward_inplace(self, x):
         self._run(x, False)
 
-    # ntt.rs:31-35,45-49: the LAZY const parameter is never read, lazy == strict
-    forward_inplace_lazy = forward_inplace
-    backward_inplace_lazy = backward_inplace
+    # ntt.rs:31-35, 45-49: "elements in [0, 2q)".  The reference never reads its LAZY parameter, so
+    # it returns canonical residues here too; this engine skips the last conditional subtractions
+    # where its arithmetic is lazy (q < 2^61) and returns the canonical residues otherwise.
+    def forward_inplace_lazy(self, x):
+        self._run(x, True, lazy=True)
+
+    def backward_inplace_lazy(self, x):
+        self._run(x, False, lazy=True)
 
     def forward_inplace_core(self, x, lazy=False):
-        self._run(x, True)
+        self._run(x, True, lazy)
 
     def backward_inplace_core(self, x, lazy=False):
-        self._run(x, False)
+        self._run(x, False, lazy)
 
     # batched host path (no counterpart in the reference, which loops over slices)
     def forward_inplace_batch(self, x, batch):

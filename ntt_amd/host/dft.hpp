@@ -70,12 +70,16 @@ class PlanHolder {
 
 // Length semantics: the reference sizes the transform by the slice (ntt.rs:123), but only
 // len == n round-trips (ntt.rs:231-235) and len > n indexes out of bounds (ntt.rs:143).
-inline void run(const nttx_plan* plan, uint64_t n, void* x, size_t len, bool forward)
+// lazy: outputs in [0, 2q) as the reference documents for its *_lazy methods (ntt.rs:31-35, 45-49)
+inline void run(const nttx_plan* plan, uint64_t n, void* x, size_t len, bool forward, bool lazy = false)
 {
     if (len != n)
         throw Panic("slice length does not match the table size");
-    check(forward ? nttx_forward_host(plan, static_cast<uint64_t*>(x), 1)
-                  : nttx_backward_host(plan, static_cast<uint64_t*>(x), 1));
+    uint64_t* a = static_cast<uint64_t*>(x);
+    if (lazy)
+        check(forward ? nttx_forward_host_lazy(plan, a, 1) : nttx_backward_host_lazy(plan, a, 1));
+    else
+        check(forward ? nttx_forward_host(plan, a, 1) : nttx_backward_host(plan, a, 1));
 }
 
 // Same transform computed by n_shards shards over the plan's devices (one exchange between them);
@@ -150,11 +154,12 @@ class Table<uint64_t> : public DFT<uint64_t> {
     void backward_inplace(uint64_t* a, size_t len) const override { backward_inplace_core<false>(a, len); }    // ntt.rs:41-43
     void backward_inplace_lazy(uint64_t* a, size_t len) const override { backward_inplace_core<true>(a, len); } // ntt.rs:48-50
 
-    // ntt.rs:122, 178 -- LAZY is accepted and ignored, as in the reference
+    // ntt.rs:122, 178.  The reference accepts LAZY and ignores it; here it selects the entry points
+    // whose outputs lie in [0, 2q), the range its lazy methods document (ntt.rs:31-35, 45-49)
     template <bool LAZY>
-    void forward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true); }
+    void forward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true, LAZY); }
     template <bool LAZY>
-    void backward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false); }
+    void backward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false, LAZY); }
 
     void forward_inplace_distributed(uint64_t* a, size_t len, int n_shards = 0) const
     {
@@ -225,9 +230,9 @@ class TableAVX2 : public DFT<int64_t> {
     void backward_inplace_lazy(int64_t* a, size_t len) const override { backward_inplace_core<true>(a, len); }
 
     template <bool LAZY>
-    void forward_inplace_core(int64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true); }   // :108
+    void forward_inplace_core(int64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true, LAZY); }   // :108
     template <bool LAZY>
-    void backward_inplace_core(int64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false); } // :281
+    void backward_inplace_core(int64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false, LAZY); } // :281
 
     void forward_inplace_distributed(int64_t* a, size_t len, int n_shards = 0) const
     {
@@ -301,9 +306,9 @@ class TableGoldilock<uint64_t> : public DFT<uint64_t> {
     void backward_inplace_lazy(uint64_t* a, size_t len) const override { backward_inplace_core<true>(a, len); }
 
     template <bool LAZY>
-    void forward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true); }   // :81
+    void forward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true, LAZY); }   // :81
     template <bool LAZY>
-    void backward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false); } // :128
+    void backward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false, LAZY); } // :128
 
     void forward_inplace_distributed(uint64_t* a, size_t len, int n_shards = 0) const
     {

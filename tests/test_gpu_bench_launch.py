@@ -1,0 +1,38 @@
+"""bench.py starts its own ranks: `python bench.py --gpus 2 ...` with no RANK in the environment must
+launch two processes (before touching a GPU), run the batch-sharded loop of the reference's README
+shape (src/main.rs:26-54) on each, and print ONE JSON line.  On a one-GPU box both ranks share
+device 0 and line up over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "mont16", "--steps", "2",
+           "--warmup", "1", "--kernel-reps", "1", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_two_ranks_weak():
+    rec = _run(["--batch", "64"])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
+    assert rec["config"]["batch_per_gpu"] == 64 and rec["config"]["job_batch"] == 128
+    assert rec["value"] > 0 and rec["steps"] == 2
+    assert abs(rec["value"] - 128 * 2 / (rec["ms_per_step"] * 2e-3)) / rec["value"] < 1e-3
+
+
+def test_two_ranks_strong():
+    rec = _run(["--total-batch", "97"])  # ragged: 49 + 48
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong"
+    assert rec["config"]["job_batch"] == 97 and rec["config"]["batch_per_gpu"] == 49

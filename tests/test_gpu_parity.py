@@ -168,16 +168,18 @@ def test_normal_case(amd):  # ntt.rs:279-295 (`2 ^ 61` is XOR: inputs in 0..63)
     assert np.array_equal(a_clone, a)
 
 
-def test_lazy_methods_equal_strict(amd):  # ntt.rs:31-35: LAZY is never read
+def test_lazy_methods_agree_with_strict(amd):
+    """ntt.rs:31-35, 45-49: the lazy methods promise [0, 2q); the reference never reads LAZY and
+    returns canonical residues, this engine returns values congruent to them below 2q."""
     table = amd.Table.new()
     a = orc.splitmix_residues(Q61, 1 << 16, 15)
     b = a.copy()
     table.forward_inplace(a)
     table.forward_inplace_lazy(b)
-    assert np.array_equal(a, b)
+    assert int(b.max()) < 2 * Q61 and np.array_equal(a, b % np.uint64(Q61))
     table.backward_inplace(a)
     table.backward_inplace_lazy(b)
-    assert np.array_equal(a, b)
+    assert int(b.max()) < 2 * Q61 and np.array_equal(a, b % np.uint64(Q61))
 
 
 @pytest.mark.parametrize("logn", [4, 8, 12, 16, 20])

@@ -42,7 +42,7 @@ def composition(ref, q, a, b, n):
         fa, fb = a[i * n:(i + 1) * n].copy(), b[i * n:(i + 1) * n].copy()
         ref.forward_inplace(fa)
         ref.forward_inplace(fb)
-        prod = np.array([int(x) * int(y) % q for x, y in zip(fa, fb)], dtype=np.uint64)
+        prod = (fa.astype(object) * fb.astype(object) % q).astype(np.uint64)
         ref.backward_inplace(prod)
         out[i * n:(i + 1) * n] = prod
     return out
@@ -80,7 +80,7 @@ def test_schoolbook(amd, kind, n):
 
 
 @pytest.mark.parametrize("kind", ["mont61", "montwide", "goldilocks"])
-@pytest.mark.parametrize("logn,batch", [(8, 3), (12, 17), (16, 1), (16, 40)])
+@pytest.mark.parametrize("logn,batch", [(8, 3), (10, 5), (12, 17), (16, 1), (16, 40), (18, 3), (20, 2)])
 def test_matches_composition_host_and_device(amd, kind, logn, batch):
     import torch
     n = 1 << logn
@@ -126,6 +126,9 @@ def test_square_and_overlap(amd):
     big = torch.zeros(3 * n, dtype=torch.int64, device="cuda")
     with pytest.raises(amd.Panic):
         gpu.negacyclic_mul_inplace(big[:2 * n], big[n:])     # partial overlap
+    hbig = np.zeros(3 * n, dtype=np.uint64)
+    with pytest.raises(amd.Panic):
+        gpu.negacyclic_mul_inplace(hbig[:2 * n], hbig[n:])   # the host entry point refuses it too
 
 
 def test_goldilocks_product_after_forward_emits_q(amd):

@@ -2,7 +2,10 @@
 <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <tag>_pmc.txt (mean counter per kernel),
 traffic_<workload>.json (HBM bytes per launch: FETCH_SIZE KB x 1024 x 2 -- gfx950 tallies a
 128-byte read request as 64 bytes -- plus WRITE_SIZE KB x 1024)."""
-import collections, csv, glob, json, os, re, shutil, sys
+import collections, csv, glob, json, os, re, shutil, subprocess, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_stamp  # the stamp bench.py checks before quoting these files
 
 tag, workload = sys.argv[1], sys.argv[2]
 src = os.path.join("gpurun_out", tag)
@@ -13,10 +16,10 @@ shutil.copy(src + "/bench.json", "profiles/%s_bench.json" % tag)
 
 
 def short(name):
-    m = re.search(r"fused_small_kernel<nttx::(\w+(?:<\w+>)?), (\w+), (\d)>", name)
+    m = re.search(r"fused_small_kernel<nttx::(.+?), (\w+), (\d)>\(", name)
     if m:  # bench.py calls it "fwd fused 4+8 stages ..."
         return (m.group(1), "fwd" if m.group(2) == "true" else "bwd", "fused", int(m.group(3)), 8)
-    m = re.search(r"pass_kernel<nttx::(\w+(?:<\w+>)?), (\w+), (\w+), (\d), (\d)(?:, (\w+))?>", name)
+    m = re.search(r"pass_kernel<nttx::(.+?), (\w+), (\w+), (\d), (\d)(?:, (\w+))?>\(", name)
     if not m:
         return None
     return (m.group(1), "fwd" if m.group(2) == "true" else "bwd", "contig" if m.group(3) == "true" else "strided",
@@ -52,6 +55,14 @@ for kern in bench["roofline"]["kernels"]:
     traffic[name] = int(fetch * 1024 * 2 + write * 1024)
     if (k, "SQ_INSTS_VALU") in acc:
         valu[name] = int(sum(acc[(k, "SQ_INSTS_VALU")]) / len(acc[(k, "SQ_INSTS_VALU")]))
+try:
+    sha = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    sha = "unknown"
+for rec in (traffic, valu):
+    rec["_stamp"] = kernel_source_stamp()  # hash of ntt_amd/csrc/*.hpp, *.hip at measurement time
+    rec["_git"] = sha                      # commit the working tree was based on (informational)
+    rec["_source"] = "gpurun_out/%s -> profiles/%s_pmc.txt" % (tag, tag)
 json.dump(traffic, open("profiles/traffic_%s.json" % workload, "w"), indent=1)
 json.dump(valu, open("profiles/valu_%s.json" % workload, "w"), indent=1)
 print(json.dumps(traffic, indent=1))
