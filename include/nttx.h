@@ -125,6 +125,20 @@ int nttx_forward_device(const nttx_plan *plan, int device, void *dptr, size_t ba
 int nttx_backward_device(const nttx_plan *plan, int device, void *dptr, size_t batch, void *hip_stream);
 
 /*
+ * nttx_forward_host (dir = 0) / nttx_backward_host (dir = 1) for callers that cannot allocate.
+ * No counterpart in the reference.  It is for harnesses that forbid hipMalloc, tight serving loops
+ * and similar callers: the batch is staged in a 32 MiB array that is part of the library's code
+ * object (every GPU the library runs on holds one from load time to process exit), and the call
+ * makes no hipMalloc, hipFree, stream or event: copies and kernels run on the default stream of the
+ * plan's FIRST device, and the call returns when the result is back in `data`.  Results are those of
+ * nttx_forward_host / nttx_backward_host bit for bit.  batch * n * 8 bytes must not exceed 32 MiB
+ * (64 vectors of 2^16, one of 2^22): larger calls fail with NTTX_EINVAL.  Every call on a GPU
+ * shares that GPU's array -- the upload overwrites whatever the last call left there, nothing needs
+ * clearing -- so calls that overlap in time on one GPU (from any thread or plan) race; serialise them.
+ */
+int nttx_transform_host_noalloc(const nttx_plan *plan, uint64_t *data, size_t batch, int dir);
+
+/*
  * The same transforms with LAZY outputs: DFT::forward_inplace_lazy / backward_inplace_lazy
  * (dft.rs:8,10), whose contract is "elements in [0, 2q)" (ntt.rs:31-35, 45-49; the reference's
  * LAZY parameter is never read, so its lazy methods return canonical residues, which satisfy that

@@ -23,6 +23,7 @@ SYMBOLS = {
     "nttx_backward_host": (C.c_int, [_vp, _vp, _sz]),
     "nttx_forward_device": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp]),
     "nttx_backward_device": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp]),
+    "nttx_transform_host_noalloc": (C.c_int, [_vp, _vp, _sz, C.c_int]),
     "nttx_plan_policy": (C.c_char_p, [_vp]),
     "nttx_forward_host_lazy": (C.c_int, [_vp, _vp, _sz]),
     "nttx_backward_host_lazy": (C.c_int, [_vp, _vp, _sz]),

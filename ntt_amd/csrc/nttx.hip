@@ -1318,6 +1318,83 @@ int nttx_negacyclic_mul_device(const nttx_plan* plan, int device, void* a, void*
     return rc;
 }
 
+} // extern "C"
+
+// ---- host-slice transform that allocates nothing ------------------------------------------------
+//
+// Staging memory of nttx_transform_host_noalloc: part of the code object, so every GPU the library
+// runs on holds its own copy from the moment the module is loaded until the process ends.  In host
+// code the array's name is only a handle for hipGetSymbolAddress; the address kernels and copies
+// use is looked up once per device, with that device current, and kept in scratch_ptr.
+namespace {
+constexpr size_t NOALLOC_MAX_BYTES = 32ull << 20;
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static __device__ __attribute__((used)) __align__(256) uint64_t scratch[NOALLOC_MAX_BYTES / sizeof(uint64_t)];
+std::mutex scratch_lock;
+uint64_t* scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+
+// Device address of this device's copy of `scratch`; `device` must be current.
+int scratch_on_current_device(int device, uint64_t** out)
+{
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES)
+        return fail(NTTX_ENODEV, "device index out of range for the static staging buffer");
+    std::lock_guard<std::mutex> guard(scratch_lock);
+    if (!scratch_ptr[device]) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p)
+            return fail(NTTX_EHIP, "hipGetSymbolAddress returned no address for the static staging buffer");
+        scratch_ptr[device] = static_cast<uint64_t*>(p);
+    }
+    *out = scratch_ptr[device];
+    return NTTX_OK;
+}
+} // namespace
+
+extern "C" {
+
+int nttx_transform_host_noalloc(const nttx_plan* plan, uint64_t* data, size_t batch, int dir)
+{
+    if (!plan)
+        return fail(NTTX_EINVAL, "plan is NULL");
+    if (dir != 0 && dir != 1)
+        return fail(NTTX_EINVAL, "direction must be 0 (forward) or 1 (backward)");
+    if (batch == 0)
+        return NTTX_OK;
+    if (!data)
+        return fail(NTTX_EINVAL, "data is NULL");
+    const size_t max_batch = NOALLOC_MAX_BYTES >> (plan->logn + 3);
+    if (batch > max_batch)
+        return fail(NTTX_EINVAL, "batch * n * 8 bytes exceeds the static staging buffer of 32 MiB "
+                                 "(use nttx_forward_host / nttx_backward_host, which allocate)");
+    const size_t bytes = (batch << plan->logn) * sizeof(uint64_t);
+    const int device = plan->devices[0];
+    int prev = -1;
+    HIP_TRY(hipGetDevice(&prev));
+    if (prev != device)
+        HIP_TRY(hipSetDevice(device));
+    auto body = [&]() -> int {
+        uint64_t* ptr = nullptr;
+        int rc = scratch_on_current_device(device, &ptr);
+        if (rc != NTTX_OK)
+            return rc;
+        // everything on the default stream: no stream, event or buffer is created
+        HIP_TRY(hipMemcpyAsync(ptr, data, bytes, hipMemcpyHostToDevice, nullptr));
+        rc = enqueue(plan, 0, ptr, batch, dir == 0, nullptr);
+        if (rc != NTTX_OK) {
+            (void)hipStreamSynchronize(nullptr);
+            return rc;
+        }
+        HIP_TRY(hipMemcpyAsync(data, ptr, bytes, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        return NTTX_OK;
+    };
+    const int rc = body();
+    if (prev != device && prev >= 0)
+        (void)hipSetDevice(prev);
+    return rc;
+}
+
 int nttx_pass_count(const nttx_plan* plan) { return plan ? (int)plan->passes.size() : 0; }
 
 int nttx_pass_describe(const nttx_plan* plan, int dir, int pass_index, char* buf, size_t buf_len)
