@@ -101,9 +101,10 @@ const char *nttx_plan_policy(const nttx_plan *plan);
  * In-place transforms of `batch` independent length-n vectors stored back to back in HOST
  * memory (batch*n u64, little endian).  batch == 1 is DFT::forward_inplace / backward_inplace
  * (dft.rs:7,9) for Table<u64> (ntt.rs:27-29, 41-43), TableAVX2 (ntt_avx2.rs:30-32, 44-46; pass
- * the i64 slice reinterpreted) and TableGoldilock<u64> (ntt_goldilock.rs:21-23, 35-37); the
- * *_lazy trait methods (dft.rs:8,10) bind the same symbols because the reference's LAZY flag is
- * never read (ntt.rs:122, 178).  batch > 1 has no counterpart in the reference (it loops).
+ * the i64 slice reinterpreted: same outputs as the AVX2 code for its documented inputs, residues
+ * in [0, q) -- other bit patterns are read as u64 and reduced mod q, where the AVX2 lanes are signed) and TableGoldilock<u64> (ntt_goldilock.rs:21-23, 35-37); the
+ * *_lazy trait methods (dft.rs:8,10) may bind the same symbols (the reference's LAZY flag is never
+ * read, ntt.rs:122, 178) or the *_lazy entry points below.  batch > 1 has no counterpart in the reference (it loops).
  * Copies to the plan's devices, splits the batch evenly across them, transforms, copies back.
  * Forward: natural order in, bit-reversed order out.  Backward: bit-reversed in, natural out,
  * scaled by n^-1.

@@ -28,19 +28,36 @@ extern "C" {
         devices: *const c_int, n_devices: c_int, out: *mut *mut NttxPlan,
     ) -> c_int;
     pub fn nttx_plan_destroy(plan: *mut NttxPlan);
+    pub fn nttx_plan_info(plan: *const NttxPlan, kind: *mut c_int, q: *mut u64, k: *mut u64, n: *mut u64,
+                          n_inv: *mut u64, n_devices: *mut c_int) -> c_int;
+    pub fn nttx_plan_tables(plan: *const NttxPlan, psi_bo_out: *mut u64, psi_inv_bo_out: *mut u64) -> c_int;
+    pub fn nttx_plan_policy(plan: *const NttxPlan) -> *const c_char;
     pub fn nttx_forward_host(plan: *const NttxPlan, data: *mut u64, batch: usize) -> c_int;
     pub fn nttx_backward_host(plan: *const NttxPlan, data: *mut u64, batch: usize) -> c_int;
-    pub fn nttx_forward_device(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, stream: *mut c_void) -> c_int;
-    pub fn nttx_backward_device(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, stream: *mut c_void) -> c_int;
+    pub fn nttx_forward_device(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, hip_stream: *mut c_void) -> c_int;
+    pub fn nttx_backward_device(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, hip_stream: *mut c_void) -> c_int;
+    /// forward_host / backward_host staged through a static device array: no allocation, at most 32 MiB.
+    pub fn nttx_transform_host_noalloc(plan: *const NttxPlan, data: *mut u64, batch: usize, dir: c_int) -> c_int;
+    /// Outputs in [0, 2q): what DFT::forward_inplace_lazy / backward_inplace_lazy document (ntt.rs:31-35, 45-49).
+    pub fn nttx_forward_host_lazy(plan: *const NttxPlan, data: *mut u64, batch: usize) -> c_int;
+    pub fn nttx_backward_host_lazy(plan: *const NttxPlan, data: *mut u64, batch: usize) -> c_int;
+    pub fn nttx_forward_device_lazy(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, hip_stream: *mut c_void) -> c_int;
+    pub fn nttx_backward_device_lazy(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, hip_stream: *mut c_void) -> c_int;
     pub fn nttx_negacyclic_mul_host(plan: *const NttxPlan, a: *mut u64, b: *const u64, batch: usize) -> c_int;
-    pub fn nttx_negacyclic_mul_device(plan: *const NttxPlan, device: c_int, a: *mut c_void, b: *mut c_void, batch: usize, stream: *mut c_void) -> c_int;
+    pub fn nttx_negacyclic_mul_device(plan: *const NttxPlan, device: c_int, a: *mut c_void, b: *mut c_void, batch: usize, hip_stream: *mut c_void) -> c_int;
+    pub fn nttx_pass_count(plan: *const NttxPlan) -> c_int;
+    pub fn nttx_pass_describe(plan: *const NttxPlan, dir: c_int, pass_index: c_int, buf: *mut c_char, buf_len: usize) -> c_int;
+    pub fn nttx_run_pass_device(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, dir: c_int,
+                                pass_index: c_int, hip_stream: *mut c_void) -> c_int;
     pub fn nttx_forward_distributed(plan: *const NttxPlan, host_data: *mut u64, n_shards: c_int) -> c_int;
     pub fn nttx_backward_distributed(plan: *const NttxPlan, host_data: *mut u64, n_shards: c_int) -> c_int;
     pub fn nttx_shard_geometry(plan: *const NttxPlan, n_shards: c_int, local_elems: *mut u64, rows: *mut u64,
                                cols: *mut u64, rows_per_peer: *mut u64) -> c_int;
     pub fn nttx_shard_phase_device(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, dir: c_int, phase: c_int,
-                                   shard: c_int, n_shards: c_int, stream: *mut c_void) -> c_int;
+                                   shard: c_int, n_shards: c_int, hip_stream: *mut c_void) -> c_int;
+    pub fn nttx_device_count() -> c_int;
     pub fn nttx_last_error() -> *const c_char;
+    pub fn nttx_version() -> *const c_char;
 }
 
 /// Owned plan handle.  A plan is immutable after creation and the library allows concurrent
@@ -83,5 +100,14 @@ impl Plan {
     pub fn backward(&self, a: &mut [u64], n: u64) {
         assert_eq!(a.len() as u64, n, "slice length does not match the table size");
         check(unsafe { nttx_backward_host(self.0, a.as_mut_ptr(), 1) });
+    }
+    /// `*_inplace_core::<true>`: outputs in [0, 2q) (ntt.rs:31-35, 45-49).
+    pub fn forward_lazy(&self, a: &mut [u64], n: u64) {
+        assert_eq!(a.len() as u64, n, "slice length does not match the table size");
+        check(unsafe { nttx_forward_host_lazy(self.0, a.as_mut_ptr(), 1) });
+    }
+    pub fn backward_lazy(&self, a: &mut [u64], n: u64) {
+        assert_eq!(a.len() as u64, n, "slice length does not match the table size");
+        check(unsafe { nttx_backward_host_lazy(self.0, a.as_mut_ptr(), 1) });
     }
 }
