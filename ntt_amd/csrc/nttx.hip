@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -161,9 +162,13 @@ struct nttx_plan {
     // which the Montgomery-kind kernels form as a * b * 2^-64 (nttx_negacyclic_mul_*)
     nttx::MontCtx mctx_mul{};
     nttx::Shoup61Ctx sctx_mul{};
-    std::vector<uint64_t> h_fwd, h_inv;       // tables as the caller passed them
-    std::vector<nttx::TwPair> h_fwd2, h_inv2; // SHOUP61: plain twiddle + quotient
-    std::vector<uint64_t> h_fwd_plain, h_inv_plain; // GOLDILOCKS_CANONICAL: twiddles out of Montgomery form
+    // Tables in the reference's format (powers_psi_bo / powers_psi_inv_bo: Montgomery form for
+    // NTTX_MONT64, plain for NTTX_GOLDILOCKS), as the caller passed them.  Empty when the plan
+    // generated its tables on the devices (from_root with n >= DEVICE_TABLES_MIN_N): nttx_plan_tables
+    // then rebuilds them on the host from (q, psi, n).
+    std::vector<uint64_t> h_fwd, h_inv;
+    uint64_t psi = 0;     // root the plan was created from (generated tables only)
+    bool exact_k = false; // created by nttx_plan_create_from_root_exact_k
     std::vector<int> devices;
     std::vector<void*> d_fwd, d_inv;           // per device: tables in the reference's index order
     std::vector<void*> d_fwd_perm, d_inv_perm; // per device: last four stages regrouped (permuted_index)
@@ -922,7 +927,56 @@ __global__ void regroup_kernel(const E* __restrict__ src, E* __restrict__ dst, u
         dst[nttx::permuted_index(i, logn)] = src[i];
 }
 
-int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
+// One level of the doubling recurrence of host/tables.hpp (fill_bit_reversed_powers):
+// tab[half + j] = tab[j] * s for j < half, s = g^(n / 2 half).  The products are the canonical
+// residues the reference's chain stores (ntt.rs:251-258: REDC products; ntt_goldilock.rs:205-211:
+// mul_reduce), so the table equals the host-built one bit for bit.
+__global__ void table_level_kernel(uint64_t* tab, uint64_t half, uint64_t s, int goldilocks, nttx::MontCtx c)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < half)
+        tab[half + j] = goldilocks ? nttx::Goldilocks::mul_strict(tab[j], s) : nttx::Mont<true>::mul(tab[j], s, c);
+}
+
+// Montgomery-form table -> the lazy policies' (plain twiddle, quotient) pairs:
+// w = REDC(raw) (utils.rs:165-178), v = floor(w * 2^64 / q) by restoring division (q < 2^61, so
+// the running remainder doubled stays below 2^62).
+__global__ void shoup_pairs_kernel(const uint64_t* __restrict__ raw, nttx::TwPair* __restrict__ out, uint64_t n,
+                                   nttx::MontCtx c)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint64_t w = nttx::Mont<true>::mul(raw[i], 1, c);
+    uint64_t r = w, v = 0;
+    for (int bit = 0; bit < 64; bit++) {
+        r <<= 1;
+        const bool ge = r >= c.q;
+        r -= ge ? c.q : 0;
+        v = (v << 1) | (ge ? 1u : 0u);
+    }
+    out[i] = nttx::TwPair{w, v};
+}
+
+// Montgomery-form table -> plain residues, in place (GOLDILOCKS_CANONICAL)
+__global__ void plain_residues_kernel(uint64_t* tab, uint64_t n, nttx::MontCtx c)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        tab[i] = nttx::Mont<true>::mul(tab[i], 1, c);
+}
+
+// Where a plan's tables come from: host arrays in the reference's format, or the seeds of the
+// doubling recurrence (the first `seed` entries, built on the host, and one factor per further level).
+struct TableSource {
+    const uint64_t* h_fwd = nullptr;
+    const uint64_t* h_inv = nullptr;
+    uint64_t seed = 0;                       // generated: entries [0, seed) come from seed_fwd / seed_inv
+    std::vector<uint64_t> seed_fwd, seed_inv;
+    std::vector<uint64_t> step_fwd, step_inv; // step[k] = g^(n / 2^(k+1)), k = log2(seed) .. log2(n) - 1
+};
+
+int finish_plan(nttx_plan* plan, const TableSource& src, const int* devices, int n_devices)
 {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -943,14 +997,12 @@ int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
     int prev = 0;
     (void)hipGetDevice(&prev);
     const bool pairs = plan->policy == nttx_plan::SHOUP61 || plan->policy == nttx_plan::SHOUP61_NEAR;
-    const size_t esz = pairs ? sizeof(nttx::TwPair) : sizeof(uint64_t);
-    const size_t bytes = plan->n * esz;
     const bool plain = plan->policy == nttx_plan::GOLDILOCKS_CANONICAL;
-    const char* src_fwd = pairs ? (const char*)plan->h_fwd2.data()
-                                : plain ? (const char*)plan->h_fwd_plain.data() : (const char*)plan->h_fwd.data();
-    const char* src_inv = pairs ? (const char*)plan->h_inv2.data()
-                                : plain ? (const char*)plan->h_inv_plain.data() : (const char*)plan->h_inv.data();
+    const bool goldilocks = plan->kind == NTTX_GOLDILOCKS;
+    const size_t raw_bytes = plan->n * sizeof(uint64_t);
+    const size_t bytes = plan->n * (pairs ? sizeof(nttx::TwPair) : sizeof(uint64_t));
     const size_t nd = plan->devices.size();
+    const unsigned grid = (unsigned)((plan->n + 255) / 256);
     plan->host_slots.clear();
     for (size_t i = 0; i < nd; i++)
         plan->host_slots.emplace_back(new nttx_plan::HostSlot);
@@ -960,29 +1012,48 @@ int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
     plan->d_inv_perm.assign(nd, nullptr);
     for (size_t i = 0; i < nd; i++) {
         HIP_TRY(hipSetDevice(plan->devices[i]));
-        HIP_TRY(hipMalloc(&plan->d_fwd[i], bytes));
-        HIP_TRY(hipMalloc(&plan->d_inv[i], bytes));
         HIP_TRY(hipMalloc(&plan->d_fwd_perm[i], bytes));
         HIP_TRY(hipMalloc(&plan->d_inv_perm[i], bytes));
-        HIP_TRY(hipMemcpy(plan->d_fwd[i], src_fwd, bytes, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(plan->d_inv[i], src_inv, bytes, hipMemcpyHostToDevice));
-        // regrouped copies for the pass that holds the last four stages, made on the device
-        const unsigned grid = (unsigned)((plan->n + 255) / 256);
-        (void)hipGetLastError();
-        if (pairs) {
-            using E = nttx::TwPair;
-            hipLaunchKernelGGL(regroup_kernel<E>, dim3(grid), dim3(256), 0, nullptr, static_cast<const E*>(plan->d_fwd[i]),
-                               static_cast<E*>(plan->d_fwd_perm[i]), plan->n, plan->logn);
-            hipLaunchKernelGGL(regroup_kernel<E>, dim3(grid), dim3(256), 0, nullptr, static_cast<const E*>(plan->d_inv[i]),
-                               static_cast<E*>(plan->d_inv_perm[i]), plan->n, plan->logn);
-        } else {
-            using E = uint64_t;
-            hipLaunchKernelGGL(regroup_kernel<E>, dim3(grid), dim3(256), 0, nullptr, static_cast<const E*>(plan->d_fwd[i]),
-                               static_cast<E*>(plan->d_fwd_perm[i]), plan->n, plan->logn);
-            hipLaunchKernelGGL(regroup_kernel<E>, dim3(grid), dim3(256), 0, nullptr, static_cast<const E*>(plan->d_inv[i]),
-                               static_cast<E*>(plan->d_inv_perm[i]), plan->n, plan->logn);
+        for (int dir = 0; dir < 2; dir++) {
+            // the table in the reference's format: copied from the caller, or generated here
+            uint64_t* raw = nullptr;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&raw), raw_bytes));
+            void*& table = dir == 0 ? plan->d_fwd[i] : plan->d_inv[i];
+            table = raw; // owned by the plan from here on (freed with it if anything below fails)
+            (void)hipGetLastError();
+            if (src.seed == 0) {
+                HIP_TRY(hipMemcpy(raw, dir == 0 ? src.h_fwd : src.h_inv, raw_bytes, hipMemcpyHostToDevice));
+            } else {
+                const std::vector<uint64_t>& seeds = dir == 0 ? src.seed_fwd : src.seed_inv;
+                const std::vector<uint64_t>& step = dir == 0 ? src.step_fwd : src.step_inv;
+                HIP_TRY(hipMemcpy(raw, seeds.data(), src.seed * sizeof(uint64_t), hipMemcpyHostToDevice));
+                size_t level = 0;
+                for (uint64_t half = src.seed; half < plan->n; half <<= 1, level++)
+                    hipLaunchKernelGGL(table_level_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, nullptr, raw,
+                                       half, step[level], goldilocks ? 1 : 0, plan->mctx);
+            }
+            // the table in the kernels' format
+            if (pairs) {
+                nttx::TwPair* tw = nullptr;
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tw), bytes));
+                hipLaunchKernelGGL(shoup_pairs_kernel, dim3(grid), dim3(256), 0, nullptr, raw, tw, plan->n, plan->mctx);
+                const hipError_t e = hipDeviceSynchronize();
+                table = tw;
+                (void)hipFree(raw);
+                HIP_TRY(e);
+            } else if (plain) {
+                hipLaunchKernelGGL(plain_residues_kernel, dim3(grid), dim3(256), 0, nullptr, raw, plan->n, plan->mctx);
+            }
+            // regrouped copy for the pass that holds the last four stages
+            void* perm = dir == 0 ? plan->d_fwd_perm[i] : plan->d_inv_perm[i];
+            if (pairs)
+                hipLaunchKernelGGL(regroup_kernel<nttx::TwPair>, dim3(grid), dim3(256), 0, nullptr,
+                                   static_cast<const nttx::TwPair*>(table), static_cast<nttx::TwPair*>(perm), plan->n, plan->logn);
+            else
+                hipLaunchKernelGGL(regroup_kernel<uint64_t>, dim3(grid), dim3(256), 0, nullptr,
+                                   static_cast<const uint64_t*>(table), static_cast<uint64_t*>(perm), plan->n, plan->logn);
+            HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
     }
     // The split transform exchanges pieces between the plan's devices: let them reach each other's
@@ -1000,49 +1071,15 @@ int finish_plan(nttx_plan* plan, const int* devices, int n_devices)
         }
     }
     (void)hipSetDevice(prev);
-    // the derived tables now live on the devices; only the caller's tables stay for nttx_plan_tables
-    std::vector<nttx::TwPair>().swap(plan->h_fwd2);
-    std::vector<nttx::TwPair>().swap(plan->h_inv2);
-    std::vector<uint64_t>().swap(plan->h_fwd_plain);
-    std::vector<uint64_t>().swap(plan->h_inv_plain);
     return NTTX_OK;
 }
 
-} // namespace
-
-extern "C" {
-
-int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_inv, const uint64_t* psi_bo,
-                     const uint64_t* psi_inv_bo, const int* devices, int n_devices, nttx_plan** out)
+// Everything of plan creation but the origin of the tables.  psi1 / psi_inv1: entry 1 of the two
+// tables (reference format).
+int create_plan(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_inv, const TableSource& src, const int* devices,
+                int n_devices, nttx_plan** out)
 {
-    if (!out)
-        return fail(NTTX_EINVAL, "out is NULL");
-    *out = nullptr;
-    if (kind != NTTX_MONT64 && kind != NTTX_GOLDILOCKS)
-        return fail(NTTX_EINVAL, "unknown kind");
-    if (!psi_bo || !psi_inv_bo)
-        return fail(NTTX_EINVAL, "twiddle tables are NULL");
-    if (n < 4 || n > (1ull << 32) || (n & (n - 1)) != 0)
-        return fail(NTTX_EINVAL, "n must be a power of two in [4, 2^32]");
     const uint32_t logn = ntt::host::ilog2(n);
-    if (logn % 2 != 0)
-        return fail(NTTX_EINVAL, "log2(n) must be even: the reference's bit_reverse (utils.rs:14-17) "
-                                 "indexes out of bounds for odd log2(n)");
-    if (kind == NTTX_MONT64) {
-        if ((q & 1) == 0 || q < 3)
-            return fail(NTTX_EINVAL, "modulus is not coprime to helper modulus R=2^64");
-        if (k * q != 1)
-            return fail(NTTX_EINVAL, "k * q != 1 mod 2^64: the reference derives a wrong k for this modulus "
-                                     "(utils.rs:148-152)");
-    } else if (q != nttx::Goldilocks::Q) {
-        return fail(NTTX_EINVAL, "NTTX_GOLDILOCKS requires q = 0xffffffff00000001");
-    }
-    if (n_inv >= q)
-        return fail(NTTX_EINVAL, "n_inv is not a residue");
-    for (uint64_t i = 0; i < n; i++)
-        if (psi_bo[i] >= q || psi_inv_bo[i] >= q)
-            return fail(NTTX_EINVAL, "twiddle table entry is not a residue");
-
     nttx_plan* plan = new (std::nothrow) nttx_plan;
     if (!plan)
         return fail(NTTX_ENOMEM, "out of host memory");
@@ -1068,43 +1105,30 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
     plan->mctx_mul = plan->mctx;
     plan->mctx_mul.n_inv_m = (uint64_t)(((u128)n_inv * r_mod_q) % q); // n^-1 * 2^128: REDC leaves n^-1 * 2^64
     plan->gctx = nttx::GoldilocksCtx{n_inv};
-    try {
-        plan->h_fwd.assign(psi_bo, psi_bo + n);
-        plan->h_inv.assign(psi_inv_bo, psi_inv_bo + n);
-        if (plan->policy == nttx_plan::SHOUP61 || plan->policy == nttx_plan::SHOUP61_NEAR) {
-            // The kernels multiply plain data by plain twiddles with a precomputed quotient:
-            // w = REDC(w * 2^64) (utils.rs:165-178), v = floor(w * 2^64 / q).
-            const ntt::utils::MontgomeryTransformer<uint64_t> mt{k, 0, q};
-            auto pair_of = [&](uint64_t plain) { return nttx::TwPair{plain, (uint64_t)(((u128)plain << 64) / q)}; };
-            plan->h_fwd2.resize(n);
-            plan->h_inv2.resize(n);
-            for (uint64_t i = 0; i < n; i++) {
-                plan->h_fwd2[i] = pair_of(mt.reduce((u128)psi_bo[i]));
-                plan->h_inv2[i] = pair_of(mt.reduce((u128)psi_inv_bo[i]));
-            }
-            const uint64_t n_inv_plain = mt.reduce((u128)n_inv);
-            const uint64_t s1 = (uint64_t)(((u128)plan->h_inv2[1].w * n_inv_plain) % q);
-            plan->sctx = nttx::make_shoup61_ctx(q, n_inv_plain, s1, k);
-            plan->sctx_mul = nttx::make_shoup61_ctx(q, (uint64_t)(((u128)n_inv_plain * r_mod_q) % q),
-                                                    (uint64_t)(((u128)s1 * r_mod_q) % q), k);
-        }
-        if (plan->policy == nttx_plan::GOLDILOCKS_CANONICAL) {
-            const ntt::utils::MontgomeryTransformer<uint64_t> mt{k, 0, q};
-            plan->h_fwd_plain.resize(n);
-            plan->h_inv_plain.resize(n);
-            for (uint64_t i = 0; i < n; i++) {
-                plan->h_fwd_plain[i] = mt.reduce((u128)psi_bo[i]);
-                plan->h_inv_plain[i] = mt.reduce((u128)psi_inv_bo[i]);
-            }
-            plan->gctx = nttx::GoldilocksCtx{mt.reduce((u128)n_inv)};
-        }
-    } catch (const std::bad_alloc&) {
-        delete plan;
-        return fail(NTTX_ENOMEM, "out of host memory");
+    const uint64_t psi_inv1 = src.seed ? src.seed_inv[1] : src.h_inv[1];
+    if (plan->policy == nttx_plan::SHOUP61 || plan->policy == nttx_plan::SHOUP61_NEAR) {
+        // The kernels multiply plain data by plain twiddles with a precomputed quotient; the constants
+        // leave Montgomery form here, the tables on the device (shoup_pairs_kernel).
+        const ntt::utils::MontgomeryTransformer<uint64_t> mt{k, 0, q};
+        const uint64_t n_inv_plain = mt.reduce((u128)n_inv);
+        const uint64_t s1 = (uint64_t)(((u128)mt.reduce((u128)psi_inv1) * n_inv_plain) % q);
+        plan->sctx = nttx::make_shoup61_ctx(q, n_inv_plain, s1, k);
+        plan->sctx_mul = nttx::make_shoup61_ctx(q, (uint64_t)(((u128)n_inv_plain * r_mod_q) % q),
+                                                (uint64_t)(((u128)s1 * r_mod_q) % q), k);
     }
-    plan->passes = make_schedule(logn);
-    plan->split_passes = make_passes(logn);
-    int rc = guarded([&] { return finish_plan(plan, devices, n_devices); });
+    if (plan->policy == nttx_plan::GOLDILOCKS_CANONICAL) {
+        const ntt::utils::MontgomeryTransformer<uint64_t> mt{k, 0, q};
+        plan->gctx = nttx::GoldilocksCtx{mt.reduce((u128)n_inv)};
+    }
+    int rc = guarded([&] {
+        if (src.seed == 0) {
+            plan->h_fwd.assign(src.h_fwd, src.h_fwd + n);
+            plan->h_inv.assign(src.h_inv, src.h_inv + n);
+        }
+        plan->passes = make_schedule(logn);
+        plan->split_passes = make_passes(logn);
+        return finish_plan(plan, src, devices, n_devices);
+    });
     if (rc != NTTX_OK) {
         std::string keep = g_err;
         nttx_plan_destroy(plan);
@@ -1115,6 +1139,87 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
     return NTTX_OK;
 }
 
+// Arguments every plan constructor checks.
+int check_plan_arguments(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_inv)
+{
+    if (kind != NTTX_MONT64 && kind != NTTX_GOLDILOCKS)
+        return fail(NTTX_EINVAL, "unknown kind");
+    if (n < 4 || n > (1ull << 32) || (n & (n - 1)) != 0)
+        return fail(NTTX_EINVAL, "n must be a power of two in [4, 2^32]");
+    if (ntt::host::ilog2(n) % 2 != 0)
+        return fail(NTTX_EINVAL, "log2(n) must be even: the reference's bit_reverse (utils.rs:14-17) "
+                                 "indexes out of bounds for odd log2(n)");
+    if (kind == NTTX_MONT64) {
+        if ((q & 1) == 0 || q < 3)
+            return fail(NTTX_EINVAL, "modulus is not coprime to helper modulus R=2^64");
+        if (k * q != 1)
+            return fail(NTTX_EINVAL, "k * q != 1 mod 2^64: the reference derives a wrong k for this modulus "
+                                     "(utils.rs:148-152)");
+    } else if (q != nttx::Goldilocks::Q) {
+        return fail(NTTX_EINVAL, "NTTX_GOLDILOCKS requires q = 0xffffffff00000001");
+    }
+    if (n_inv >= q)
+        return fail(NTTX_EINVAL, "n_inv is not a residue");
+    return NTTX_OK;
+}
+
+// Plans from a root generate their tables on the devices from this size on (the host builds the
+// first DEVICE_TABLES_SEED entries and the per-level factors).  NTTX_HOST_TABLES=1: never.
+constexpr uint64_t DEVICE_TABLES_MIN_N = 1ull << 18;
+constexpr uint64_t DEVICE_TABLES_SEED = 1ull << 12;
+
+} // namespace
+
+extern "C" {
+
+int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_inv, const uint64_t* psi_bo,
+                     const uint64_t* psi_inv_bo, const int* devices, int n_devices, nttx_plan** out)
+{
+    if (!out)
+        return fail(NTTX_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (kind != NTTX_MONT64 && kind != NTTX_GOLDILOCKS)
+        return fail(NTTX_EINVAL, "unknown kind");
+    if (!psi_bo || !psi_inv_bo)
+        return fail(NTTX_EINVAL, "twiddle tables are NULL");
+    int rc = check_plan_arguments(kind, q, k, n, n_inv);
+    if (rc != NTTX_OK)
+        return rc;
+    for (uint64_t i = 0; i < n; i++)
+        if (psi_bo[i] >= q || psi_inv_bo[i] >= q)
+            return fail(NTTX_EINVAL, "twiddle table entry is not a residue");
+    // Entry 0 of both tables is the unit in the table's form (ntt.rs:247-253: the chain starts from
+    // transform(1); ntt_goldilock.rs:200-206: from 1); entries 1 are psi^(n/2) and its inverse.  A
+    // table of another modulus, form or root pair fails these.
+    using u128 = unsigned __int128;
+    const uint64_t one = kind == NTTX_MONT64 ? (uint64_t)((((u128)1) << 64) % q) : 1;
+    const auto mul = [&](uint64_t a, uint64_t b) -> uint64_t {
+        if (kind == NTTX_MONT64)
+            return ntt::utils::MontgomeryTransformer<uint64_t>{k, 0, q}.mul(a, b);
+        return ntt::host::goldilocks_mul_reduce(a, b);
+    };
+    if (psi_bo[0] != one || psi_inv_bo[0] != one)
+        return fail(NTTX_EINVAL, "entry 0 of a twiddle table is not the unit (2^64 mod q for NTTX_MONT64, 1 for NTTX_GOLDILOCKS)");
+    if (mul(psi_bo[1], psi_inv_bo[1]) != one)
+        return fail(NTTX_EINVAL, "entries 1 of the twiddle tables are not inverse to each other modulo q");
+    if (mul(psi_bo[1], psi_bo[1]) != q - one)
+        return fail(NTTX_EINVAL, "entry 1 of the forward table is not a square root of -1 modulo q");
+    {
+        // n * n_inv = 1 in the table's form: n_inv * n (plain) = unit
+        uint64_t acc = n_inv; // n_inv * n by doubling (n is a power of two), canonical throughout
+        for (uint64_t m = n; m > 1; m >>= 1) {
+            const u128 d = (u128)acc * 2;
+            acc = (uint64_t)(d >= q ? d - q : d);
+        }
+        if (acc != one)
+            return fail(NTTX_EINVAL, "n_inv is not the inverse of n modulo q (in Montgomery form for NTTX_MONT64)");
+    }
+    TableSource src;
+    src.h_fwd = psi_bo;
+    src.h_inv = psi_inv_bo;
+    return create_plan(kind, q, k, n, n_inv, src, devices, n_devices, out);
+}
+
 static int plan_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n, const int* devices, int n_devices,
                           nttx_plan** out, bool exact_k)
 {
@@ -1123,7 +1228,71 @@ static int plan_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n, const 
     *out = nullptr;
     if (n < 4 || n > (1ull << 32) || (n & (n - 1)) != 0)
         return fail(NTTX_EINVAL, "n must be a power of two in [4, 2^32]");
+    static const bool host_tables = std::getenv("NTTX_HOST_TABLES") != nullptr;
     try {
+        if (n >= DEVICE_TABLES_MIN_N && !host_tables && (kind == NTTX_MONT64 || kind == NTTX_GOLDILOCKS)) {
+            // Large tables are generated on the devices: the host builds the table of the nested
+            // size-DEVICE_TABLES_SEED transform (identical to the first entries of the big table:
+            // out[j] depends on g^(n / 2^(k+1)) for 2^k <= j only) and the factor of every further level.
+            if (kind == NTTX_MONT64 ? (q < 3 || psi == 0 || psi >= q) : (q != nttx::Goldilocks::Q || psi == 0 || psi >= q))
+                return fail(NTTX_EINVAL, kind == NTTX_MONT64 ? "need 0 < psi < q" : "NTTX_GOLDILOCKS requires q = 0xffffffff00000001 and 0 < psi < q");
+            if (ntt::host::ilog2(n) % 2 != 0)
+                return fail(NTTX_EINVAL, "log2(n) must be even: the reference's bit_reverse (utils.rs:14-17) "
+                                         "indexes out of bounds for odd log2(n)");
+            const uint64_t seed = DEVICE_TABLES_SEED;
+            const uint32_t logn = ntt::host::ilog2(n), logseed = ntt::host::ilog2(seed);
+            TableSource src;
+            src.seed = seed;
+            uint64_t k = 0, n_inv = 0, g = 0, g_inv = 0;
+            std::function<uint64_t(uint64_t, uint64_t)> mul;
+            ntt::utils::MontgomeryTransformer<uint64_t> M{0, 0, q};
+            if (kind == NTTX_MONT64) {
+                // scalars exactly as build_montgomery_tables derives them (ntt.rs:90-120)
+                auto small = ntt::host::build_montgomery_tables(q, ntt::utils::mod_exp_u64(psi, n / seed, q), seed, exact_k);
+                M = small.montgomery;
+                k = M.k;
+                using ntt::utils::i128;
+                const i128 n_inv_raw = std::get<1>(ntt::utils::egcd_i128((i128)n, (i128)q));
+                n_inv = M.transform(n_inv_raw < 0 ? (uint64_t)(n_inv_raw + (i128)q) : (uint64_t)n_inv_raw);
+                const i128 psi_inv_raw = std::get<1>(ntt::utils::egcd_i128((i128)psi, (i128)q));
+                g = M.transform(psi);
+                g_inv = M.transform(psi_inv_raw < 0 ? (uint64_t)(psi_inv_raw + (i128)q) : (uint64_t)psi_inv_raw);
+                src.seed_fwd = std::move(small.powers_psi_bo);
+                src.seed_inv = std::move(small.powers_psi_inv_bo);
+                mul = [M](uint64_t a, uint64_t b) { return M.mul(a, b); };
+            } else {
+                auto small = ntt::host::build_goldilocks_tables(ntt::utils::mod_exp_u64(psi, n / seed, q), seed);
+                if ((q - 1) % n != 0)
+                    return fail(NTTX_EINVAL, "n must be a power of two dividing q - 1");
+                n_inv = q - (q - 1) / n;
+                g = psi;
+                g_inv = ntt::utils::mod_exp_u64(psi, q - 2, q);
+                src.seed_fwd = std::move(small.powers_psi_bo);
+                src.seed_inv = std::move(small.powers_psi_inv_bo);
+                mul = ntt::host::goldilocks_mul_reduce;
+            }
+            // step[k] = g^(n / 2^(k+1)) for k = logseed .. logn - 1 (fill_bit_reversed_powers)
+            auto steps = [&](uint64_t base) {
+                std::vector<uint64_t> all(logn);
+                uint64_t sq = base;
+                for (uint32_t kk = logn; kk-- > 0;) {
+                    all[kk] = sq;
+                    sq = mul(sq, sq);
+                }
+                return std::vector<uint64_t>(all.begin() + logseed, all.end());
+            };
+            src.step_fwd = steps(g);
+            src.step_inv = steps(g_inv);
+            int rc = check_plan_arguments(kind, q, k, n, n_inv);
+            if (rc != NTTX_OK)
+                return rc;
+            rc = create_plan(kind, q, k, n, n_inv, src, devices, n_devices, out);
+            if (rc == NTTX_OK) {
+                (*out)->psi = psi;
+                (*out)->exact_k = exact_k;
+            }
+            return rc;
+        }
         if (kind == NTTX_MONT64) {
             if (q < 3 || psi == 0 || psi >= q)
                 return fail(NTTX_EINVAL, "need 0 < psi < q");
@@ -1219,6 +1388,30 @@ int nttx_plan_tables(const nttx_plan* plan, uint64_t* psi_bo_out, uint64_t* psi_
 {
     if (!plan)
         return fail(NTTX_EINVAL, "plan is NULL");
+    if (plan->h_fwd.empty()) {
+        // tables were generated on the devices: the same values from the host builder
+        return guarded([&]() -> int {
+            try {
+                std::vector<uint64_t> f, b;
+                if (plan->kind == NTTX_MONT64) {
+                    auto t = ntt::host::build_montgomery_tables(plan->q, plan->psi, plan->n, plan->exact_k);
+                    f = std::move(t.powers_psi_bo);
+                    b = std::move(t.powers_psi_inv_bo);
+                } else {
+                    auto t = ntt::host::build_goldilocks_tables(plan->psi, plan->n);
+                    f = std::move(t.powers_psi_bo);
+                    b = std::move(t.powers_psi_inv_bo);
+                }
+                if (psi_bo_out)
+                    std::memcpy(psi_bo_out, f.data(), plan->n * sizeof(uint64_t));
+                if (psi_inv_bo_out)
+                    std::memcpy(psi_inv_bo_out, b.data(), plan->n * sizeof(uint64_t));
+            } catch (const ntt::Panic& p) {
+                return fail(NTTX_EINVAL, p.what());
+            }
+            return NTTX_OK;
+        });
+    }
     if (psi_bo_out)
         std::memcpy(psi_bo_out, plan->h_fwd.data(), plan->n * sizeof(uint64_t));
     if (psi_inv_bo_out)

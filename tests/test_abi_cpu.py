@@ -43,6 +43,24 @@ def test_argument_validation_needs_no_gpu():
     assert lib.nttx_plan_create_from_root(0, q61, 3, 8, None, 0, C.byref(plan)) == _lib.NTTX_EINVAL
     assert lib.nttx_plan_create_from_root(7, q61, 3, 16, None, 0, C.byref(plan)) == _lib.NTTX_EINVAL
     assert plan.value is None
+    # tables that are not a table of this modulus: every check runs before a device is touched
+    import numpy as np
+    import _oracle as orc
+    ref = orc.Table.from_prime_and_root(q61, pow(0x0B4F9CB5C38B40B1, (1 << 20) // 16, q61), 16)
+    f, b, n_inv = ref.powers_psi_bo.copy(), ref.powers_psi_inv_bo.copy(), ref.n_inv_montgomery
+
+    def create(fw, bw, ninv):
+        return lib.nttx_plan_create(0, q61, k61, 16, ninv, fw.ctypes.data, bw.ctypes.data, None, 0, C.byref(plan))
+
+    bad = f.copy(); bad[0] = 1                                   # plain 1 instead of 2^64 mod q
+    assert create(bad, b, n_inv) == _lib.NTTX_EINVAL and "entry 0" in _lib.last_error()
+    bad = f.copy(); bad[1] = f[2]
+    assert create(bad, b, n_inv) == _lib.NTTX_EINVAL and "entries 1" in _lib.last_error()
+    assert create(f, f, n_inv) == _lib.NTTX_EINVAL               # forward table passed twice
+    assert create(f, b, (n_inv + 1) % q61) == _lib.NTTX_EINVAL and "n_inv" in _lib.last_error()
+    bad = f.copy(); bad[5] = np.uint64(q61)
+    assert create(bad, b, n_inv) == _lib.NTTX_EINVAL and "residue" in _lib.last_error()
+    assert plan.value is None
     assert lib.nttx_forward_host(None, None, 1) == _lib.NTTX_EINVAL
     assert lib.nttx_version().startswith(b"nttx")
 
