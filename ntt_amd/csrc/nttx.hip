@@ -256,6 +256,53 @@ int device_slot(const nttx_plan* plan, int device)
     return -1;
 }
 
+// Environment switches, read once.  NTTX_NO_BUFFER_ADDRESSING selects the plain-pointer addressing
+// path of the kernels (an alternative code path the tests cover).  Everything else is a profiling
+// aid and is only looked at when NTTX_DEBUG is set:
+//   NTTX_DEBUG_NO_MATH=1|A|B   skip the butterflies (of one register round), keep all traffic
+//   NTTX_DEBUG_NO_TW=1         with NO_MATH: skip the twiddle loads too
+//   NTTX_DEBUG_NO_FINISH=1     skip the canonicalising end of the forward transform
+//   NTTX_XCD_GROUP=<G>         runs of G tiles per XCD on every pass (0 = plain order)
+//   NTTX_CHUNK_MIB=<m>         all passes over m MiB of the batch before the next m MiB
+// (NTTX_DEBUG_EXTRA_LDS is read next to the launches, in launch_impl.hpp.)
+struct Switches {
+    bool no_buffer = false, no_finish = false;
+    uint32_t debug_flags = 0;
+    long xcd_group = -1;
+    size_t chunk_bytes = 0;
+};
+const Switches& switches()
+{
+    static const Switches v = [] {
+        Switches s;
+        s.no_buffer = std::getenv("NTTX_NO_BUFFER_ADDRESSING") != nullptr;
+        if (std::getenv("NTTX_DEBUG") == nullptr)
+            return s;
+        if (const char* e = std::getenv("NTTX_DEBUG_NO_MATH"))
+            s.debug_flags |= e[0] == 'A' ? (uint32_t)PASS_DEBUG_NO_MATH_A : e[0] == 'B' ? (uint32_t)PASS_DEBUG_NO_MATH_B
+                                                                                        : (uint32_t)PASS_DEBUG_NO_MATH;
+        if (std::getenv("NTTX_DEBUG_NO_TW"))
+            s.debug_flags |= PASS_DEBUG_NO_TW;
+        s.no_finish = std::getenv("NTTX_DEBUG_NO_FINISH") != nullptr;
+        if (const char* e = std::getenv("NTTX_XCD_GROUP"))
+            s.xcd_group = std::atol(e);
+        if (const char* e = std::getenv("NTTX_CHUNK_MIB")) {
+            const long mib = std::atol(e);
+            s.chunk_bytes = mib <= 0 ? (size_t)0 : (size_t)mib << 20;
+        }
+        return s;
+    }();
+    return v;
+}
+// The profiling switches that act through pass flags; shared by every launch path.
+void apply_debug_flags(PassParams& p)
+{
+    const Switches& sw = switches();
+    p.flags |= sw.debug_flags;
+    if (sw.no_finish)
+        p.flags &= ~(uint32_t)PASS_FINISH;
+}
+
 // Launches pass `d` with parameters `p` (data, geometry and flags already set) over `tiles` tiles.
 // `product`: the backward transform of a pointwise product (contexts with n^-1 * 2^64).
 int launch_pass(const nttx_plan* plan, int slot, const PassDesc& d, PassParams p, uint64_t tiles, bool fwd,
@@ -265,40 +312,22 @@ int launch_pass(const nttx_plan* plan, int slot, const PassDesc& d, PassParams p
         return fail(NTTX_EINVAL, "element count is out of range for one launch");
     p.tw = fwd ? plan->d_fwd[slot] : plan->d_inv[slot];
     p.tw_perm = fwd ? plan->d_fwd_perm[slot] : plan->d_inv_perm[slot];
-    static const uint32_t no_math = [] {
-        const char* e = std::getenv("NTTX_DEBUG_NO_MATH");
-        if (!e)
-            return 0u;
-        return e[0] == 'A' ? (uint32_t)PASS_DEBUG_NO_MATH_A : e[0] == 'B' ? (uint32_t)PASS_DEBUG_NO_MATH_B
-                                                                          : (uint32_t)PASS_DEBUG_NO_MATH;
-    }();
-    p.flags |= no_math;
+    const Switches& sw = switches();
     // Every element a workgroup touches lies within 2^31 bytes of its tile's first element when a
     // block (or, for cross-batch tiles, 16 transforms) spans at most 2^28 elements.
-    static const bool no_buffer = std::getenv("NTTX_NO_BUFFER_ADDRESSING") != nullptr;
-    if (!no_buffer && ((p.flags & PASS_CROSS_BATCH) ? plan->logn + 4 <= 28 : p.logB <= 28))
+    if (!sw.no_buffer && ((p.flags & PASS_CROSS_BATCH) ? plan->logn + 4 <= 28 : p.logB <= 28))
         p.flags |= PASS_OFFSET32;
     // STRIDED passes: all tiles of a block (they share its rows, 128 bytes each) go to one XCD.
     // Measured on the headline workload: 0.80 ms instead of 0.83 ms for the memory-bound forward
-    // pass; no gain for CONTIG tiles.  NTTX_XCD_GROUP=<G> forces runs of G tiles on every pass
-    // (0 = plain order) for experiments.
-    static const long xcd_group = [] {
-        const char* e = std::getenv("NTTX_XCD_GROUP");
-        return e ? std::atol(e) : -1L;
-    }();
+    // pass; no gain for CONTIG tiles.
     uint64_t group = 0;
-    if (xcd_group >= 0)
-        group = (uint64_t)xcd_group;
+    if (sw.xcd_group >= 0)
+        group = (uint64_t)sw.xcd_group;
     else if (!d.contig && p.logB >= (uint32_t)TILE_LOG)
         group = 1ull << (p.logB - TILE_LOG);
     if (group > 0 && group <= (1u << 20) && tiles % (8 * group) == 0)
         p.xcd_group = (uint32_t)group;
-    static const bool no_finish = std::getenv("NTTX_DEBUG_NO_FINISH") != nullptr;
-    if (no_finish)
-        p.flags &= ~PASS_FINISH;
-    static const bool no_tw = std::getenv("NTTX_DEBUG_NO_TW") != nullptr;
-    if (no_tw)
-        p.flags |= PASS_DEBUG_NO_TW;
+    apply_debug_flags(p);
     hipError_t e;
     switch (plan->policy) {
     case nttx_plan::GOLDILOCKS: e = launch_pass_policy<Goldilocks>(fwd, d, p, plan->gctx, (unsigned)tiles, stream); break;
@@ -337,11 +366,14 @@ int launch_fused(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, 
     p.block_base = 0;
     p.logB = 8;
     p.s0 = plan->logn - 8;
-    p.flags = PASS_OFFSET32 | (mul_with ? (uint32_t)PASS_POINTWISE : 0u) | (lazy ? (uint32_t)PASS_LAZY : 0u);
+    // a tile of the fused launch is 4096 contiguous elements: lane offsets always fit 32 bits
+    p.flags = (switches().no_buffer ? 0u : (uint32_t)PASS_OFFSET32) | (mul_with ? (uint32_t)PASS_POINTWISE : 0u) |
+              (lazy ? (uint32_t)PASS_LAZY : 0u);
     if (fwd)
         p.flags |= PASS_FINISH | (whole ? (uint32_t)PASS_CONDITION_INPUT : 0u);
     else
         p.flags |= PASS_CONDITION_INPUT | (whole ? (uint32_t)PASS_SCALE : 0u);
+    apply_debug_flags(p);
     const bool product = mul_with != nullptr;
     hipError_t e;
     switch (plan->policy) {
@@ -522,6 +554,7 @@ int run_distributed(const nttx_plan* plan, uint64_t* host, bool fwd, int n_shard
     struct Shard {
         int dev = 0, slot = 0;
         hipStream_t s = nullptr;
+        hipEvent_t ready = nullptr;              // this shard's passes before the exchange have run
         uint64_t *col = nullptr, *blk = nullptr; // column-layout and block-layout buffers
     };
     std::vector<Shard> sh((size_t)gs);
@@ -538,12 +571,18 @@ int run_distributed(const nttx_plan* plan, uint64_t* host, bool fwd, int n_shard
         }
         return NTTX_OK;
     };
-    // piece (rho, d) of shard c's block layout <-> rows c*R + rho of shard d's column layout
+    // piece (rho, d) of shard c's block layout <-> rows c*R + rho of shard d's column layout.
+    // Copies run on the receiver's stream, each behind the sender's `ready` event only: a shard's
+    // pieces start to move as soon as that shard is done, and the receiver's next passes follow its
+    // copies in stream order -- no host synchronisation between the phases.
     auto exchange = [&](bool to_blocks) -> int {
         for (int c = 0; c < gs; c++)
             for (int d = 0; d < gs; d++) {
-                Shard& owner = to_blocks ? sh[(size_t)c] : sh[(size_t)d]; // copies run on the receiver's stream
+                Shard& owner = to_blocks ? sh[(size_t)c] : sh[(size_t)d];
+                Shard& sender = to_blocks ? sh[(size_t)d] : sh[(size_t)c];
                 HIP_TRY(hipSetDevice(owner.dev));
+                if (&owner != &sender)
+                    HIP_TRY(hipStreamWaitEvent(owner.s, sender.ready, 0));
                 for (uint64_t rho = 0; rho < g.R; rho++) {
                     uint64_t* in_blk = sh[(size_t)c].blk + (rho * (uint64_t)gs + (uint64_t)d) * g.W;
                     uint64_t* in_col = sh[(size_t)d].col + ((uint64_t)c * g.R + rho) * g.W;
@@ -562,6 +601,7 @@ int run_distributed(const nttx_plan* plan, uint64_t* host, bool fwd, int n_shard
             x.dev = plan->devices[(size_t)x.slot];
             HIP_TRY(hipSetDevice(x.dev));
             HIP_TRY(hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&x.ready, hipEventDisableTiming));
             HIP_TRY(hipMalloc(&x.col, bytes));
             HIP_TRY(hipMalloc(&x.blk, bytes));
         }
@@ -574,8 +614,9 @@ int run_distributed(const nttx_plan* plan, uint64_t* host, bool fwd, int n_shard
                                          hipMemcpyHostToDevice, x.s));
                 if ((r = enqueue_shard_phase(plan, x.slot, x.col, true, 0, d, g, x.s)) != NTTX_OK)
                     return r;
+                HIP_TRY(hipEventRecord(x.ready, x.s));
             }
-            if ((r = sync_all()) != NTTX_OK || (r = exchange(true)) != NTTX_OK || (r = sync_all()) != NTTX_OK)
+            if ((r = exchange(true)) != NTTX_OK)
                 return r;
             for (int c = 0; c < gs; c++) {
                 Shard& x = sh[(size_t)c];
@@ -591,8 +632,9 @@ int run_distributed(const nttx_plan* plan, uint64_t* host, bool fwd, int n_shard
                 HIP_TRY(hipMemcpyAsync(x.blk, host + (uint64_t)c * g.local, bytes, hipMemcpyHostToDevice, x.s));
                 if ((r = enqueue_shard_phase(plan, x.slot, x.blk, false, 1, c, g, x.s)) != NTTX_OK)
                     return r;
+                HIP_TRY(hipEventRecord(x.ready, x.s));
             }
-            if ((r = sync_all()) != NTTX_OK || (r = exchange(false)) != NTTX_OK || (r = sync_all()) != NTTX_OK)
+            if ((r = exchange(false)) != NTTX_OK)
                 return r;
             for (int d = 0; d < gs; d++) {
                 Shard& x = sh[(size_t)d];
@@ -607,13 +649,20 @@ int run_distributed(const nttx_plan* plan, uint64_t* host, bool fwd, int n_shard
     };
     rc = body();
     for (auto& x : sh) {
-        if (!x.s && !x.col && !x.blk)
+        if (!x.s && !x.col && !x.blk && !x.ready)
             continue;
         (void)hipSetDevice(x.dev);
-        if (x.s) {
+        if (x.s)
             (void)hipStreamSynchronize(x.s);
+    }
+    for (auto& x : sh) { // only after every stream has drained: streams wait on other shards' events
+        if (!x.s && !x.col && !x.blk && !x.ready)
+            continue;
+        (void)hipSetDevice(x.dev);
+        if (x.s)
             (void)hipStreamDestroy(x.s);
-        }
+        if (x.ready)
+            (void)hipEventDestroy(x.ready);
         if (x.col)
             (void)hipFree(x.col);
         if (x.blk)
@@ -623,20 +672,12 @@ int run_distributed(const nttx_plan* plan, uint64_t* host, bool fwd, int n_shard
     return rc;
 }
 
-// Optional chunking of a batch: with NTTX_CHUNK_MIB=<m> all passes run over m MiB of the batch
-// before the next m MiB, so that a pass re-reads what the previous one wrote while it may still
-// sit in the 256 MiB Infinity Cache.  Measured on MI355X this gains at most a few percent at
-// 256 MiB and loses at smaller chunks (more launch boundaries and partial waves of workgroups),
-// so the default is the whole batch per launch.
-size_t chunk_bytes()
-{
-    static const size_t v = [] {
-        const char* e = std::getenv("NTTX_CHUNK_MIB");
-        long mib = e ? std::atol(e) : 0;
-        return mib <= 0 ? (size_t)0 : (size_t)mib << 20;
-    }();
-    return v;
-}
+// Optional chunking of a batch (NTTX_DEBUG + NTTX_CHUNK_MIB=<m>): all passes run over m MiB of the
+// batch before the next m MiB, so that a pass re-reads what the previous one wrote while it may
+// still sit in the 256 MiB Infinity Cache.  Measured on MI355X this gains nothing at 256 MiB and
+// loses at smaller chunks (more launch boundaries and partial waves of workgroups), so the default
+// is the whole batch per launch.
+size_t chunk_bytes() { return switches().chunk_bytes; }
 
 // Enqueues one transform of `batch` vectors at dptr on the current device.
 // `lazy`: outputs in the arithmetic policy's lazy range instead of canonical residues.

@@ -12,9 +12,12 @@ contiguous slab; the backward transform is the mirror image.  Layouts (include/n
                            r*(n/2^f) + d*cols ... + cols of the vector
   block layout of rank c:  elements [c*n/world, (c+1)*n/world) of the vector
 
-Local stages are `nttx_shard_phase_device` launches on this rank's GPU; the exchange is
-`all_to_all_single` on device buffers over RCCL (backend "nccl").  With another backend (gloo,
-used by tests where several ranks share one GPU) the pieces are staged through host memory.
+Local stages are `nttx_shard_phase_device` launches on this rank's GPU.  The exchange runs on
+device buffers over RCCL (backend "nccl"): with few rows per peer (the N = 2^28 / 8-GPU case has
+two) as one group of point-to-point sends and receives, one message per row, each landing where
+the next phase reads it; with many rows per peer as one `all_to_all_single` of whole pieces
+followed by a reordering copy.  With another backend and GPU buffers (gloo, used by tests where
+several ranks share one GPU) the pieces are staged through host memory.
 """
 import numpy as np
 
@@ -114,6 +117,46 @@ class ShardedTransform:
             self.dist.all_to_all_single(got.view(-1), part.view(-1), group=self.group)
             r2[:, p0:p0 + step] = got
 
+    # Up to this many rows per peer the exchange is posted as rows_per_peer grouped sends and
+    # receives per peer that land where the next phase reads them; above it (many small messages)
+    # one all_to_all_single moves whole pieces and a transposing copy reorders them.
+    MAX_ROWS_DIRECT = 16
+
+    def _direct(self, x):
+        """Whether the grouped point-to-point exchange applies to buffer x."""
+        if self.world == 1 or self.rows_per_peer > self.MAX_ROWS_DIRECT:
+            return False
+        return self._device_collective or not x.is_cuda
+
+    def _exchange_rows(self, dst, src, to_blocks):
+        """The exchange without a reordering pass.  to_blocks: row c*R + rho of my column layout
+        (src) -> rank c, which stores what rank d sent at row rho*g + d of its block layout (dst).
+        Otherwise the inverse: row rho*g + d of my block layout (src) -> rank d, which stores what
+        rank c sent at row c*R + rho of its column layout (dst).  Messages between two ranks are
+        posted in the same (rho) order on both sides."""
+        g, R, W = self.world, self.rows_per_peer, self.cols
+        me = self.rank
+        if to_blocks:
+            s3, d3 = src.view(g, R, W), dst.view(R, g, W)
+            send_of = lambda peer, rho: s3[peer, rho]
+            recv_of = lambda peer, rho: d3[rho, peer]
+        else:
+            s3, d3 = src.view(R, g, W), dst.view(g, R, W)
+            send_of = lambda peer, rho: s3[rho, peer]
+            recv_of = lambda peer, rho: d3[peer, rho]
+        for rho in range(R):
+            recv_of(me, rho).copy_(send_of(me, rho))
+        ops = []
+        for peer in range(g):
+            if peer == me:
+                continue
+            gp = peer if self.group is None else self.dist.get_global_rank(self.group, peer)
+            for rho in range(R):
+                ops.append(self.dist.P2POp(self.dist.isend, send_of(peer, rho), gp, group=self.group))
+                ops.append(self.dist.P2POp(self.dist.irecv, recv_of(peer, rho), gp, group=self.group))
+        for req in self.dist.batch_isend_irecv(ops):
+            req.wait()
+
     def _check_buf(self, x):
         if x.numel() != self.local:
             raise ValueError("expected this rank's %d elements, got %d" % (self.local, x.numel()))
@@ -125,9 +168,13 @@ class ShardedTransform:
         g, R, W = self.world, self.rows_per_peer, self.cols
         self.engine.phase(col, 0, 0, self.rank, g)
         recv = torch.empty_like(col)
-        self._all_to_all(recv, col)            # piece c = my rows [c*R, (c+1)*R) -> rank c
-        # received [source d][R][W]; the block layout orders it [R][d][W]
-        blk = recv.view(g, R, W).permute(1, 0, 2).contiguous().view(-1) if (g > 1 and R > 1) else recv
+        if self._direct(col):
+            self._exchange_rows(recv, col, True)   # rows land in block-layout order
+            blk = recv
+        else:
+            self._all_to_all(recv, col)            # piece c = my rows [c*R, (c+1)*R) -> rank c
+            # received [source d][R][W]; the block layout orders it [R][d][W]
+            blk = recv.view(g, R, W).permute(1, 0, 2).contiguous().view(-1) if (g > 1 and R > 1) else recv
         self.engine.phase(blk, 0, 1, self.rank, g)
         return blk
 
@@ -137,8 +184,12 @@ class ShardedTransform:
         self._check_buf(blk)
         g, R, W = self.world, self.rows_per_peer, self.cols
         self.engine.phase(blk, 1, 1, self.rank, g)
-        send = blk.view(R, g, W).permute(1, 0, 2).contiguous().view(-1) if (g > 1 and R > 1) else blk
-        col = torch.empty_like(send)
-        self._all_to_all(col, send)            # piece d of mine -> rank d, lands as its rows [c*R, (c+1)*R)
+        if self._direct(blk):
+            col = torch.empty_like(blk)
+            self._exchange_rows(col, blk, False)   # rows land in column-layout order
+        else:
+            send = blk.view(R, g, W).permute(1, 0, 2).contiguous().view(-1) if (g > 1 and R > 1) else blk
+            col = torch.empty_like(send)
+            self._all_to_all(col, send)            # piece d of mine -> rank d, lands as its rows [c*R, (c+1)*R)
         self.engine.phase(col, 1, 0, self.rank, g)
         return col

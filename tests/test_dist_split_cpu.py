@@ -87,7 +87,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, logn, out_dir, max_elems_per_call=0):
+def _worker(rank, world, port, logn, out_dir, max_elems_per_call=0, direct_rows=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -96,6 +96,8 @@ def _worker(rank, world, port, logn, out_dir, max_elems_per_call=0):
 
     if max_elems_per_call:   # force the exchange into several collective calls
         ShardedTransform.MAX_ELEMS_PER_CALL = max_elems_per_call
+    # the grouped point-to-point exchange (rows land in place) or one collective plus a reordering copy
+    ShardedTransform.MAX_ROWS_DIRECT = direct_rows
 
     n = 1 << logn
     psi = pow(PSI32_2_17, (1 << 16) // n, Q32)
@@ -110,9 +112,10 @@ def _worker(rank, world, port, logn, out_dir, max_elems_per_call=0):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,logn,max_elems_per_call", [(2, 14, 0), (2, 16, 0), (4, 14, 0), (4, 16, 0),
-                                                          (2, 14, 1024), (4, 16, 1000)])
-def test_split_transform_matches_oracle(tmp_path, world, logn, max_elems_per_call):
+@pytest.mark.parametrize("world,logn,max_elems_per_call,direct_rows",
+                         [(2, 14, 0, 0), (2, 16, 0, 0), (4, 14, 0, 0), (4, 16, 0, 0), (2, 14, 1024, 0), (4, 16, 1000, 0),
+                          (2, 14, 0, 256), (4, 14, 0, 256), (4, 16, 0, 256), (2, 16, 0, 256)])
+def test_split_transform_matches_oracle(tmp_path, world, logn, max_elems_per_call, direct_rows):
     import _oracle as orc
     from ntt_amd.distributed import column_slab, split_geometry
 
@@ -121,7 +124,8 @@ def test_split_transform_matches_oracle(tmp_path, world, logn, max_elems_per_cal
     x = orc.splitmix_residues(Q32, n, 77)
     want = x.copy()
     orc.Table.from_prime_and_root(Q32, psi, n).forward_inplace(want)
-    mp.spawn(_worker, args=(world, _free_port(), logn, str(tmp_path), max_elems_per_call), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), logn, str(tmp_path), max_elems_per_call, direct_rows), nprocs=world,
+             join=True)
     local, rows, cols, rpp = split_geometry(n, world)
     assert local * world == n and rows * cols * world == n and rpp * world == rows
     for r in range(world):

@@ -12,9 +12,9 @@ run() { # tag, env...
 }
 run base NTTX_NONE=1
 run noxb NTTX_NO_CROSS_BATCH=1
-run chunk$1 NTTX_CHUNK_MIB=$1 NTTX_XCD_GROUP=16 NTTX_NO_CROSS_BATCH=1
-run chunk$1_nogroup NTTX_CHUNK_MIB=$1 NTTX_NO_CROSS_BATCH=1
-export NTTX_CHUNK_MIB=$1 NTTX_XCD_GROUP=16 NTTX_NO_CROSS_BATCH=1
+run chunk$1 NTTX_DEBUG=1 NTTX_CHUNK_MIB=$1 NTTX_XCD_GROUP=16 NTTX_NO_CROSS_BATCH=1
+run chunk$1_nogroup NTTX_DEBUG=1 NTTX_CHUNK_MIB=$1 NTTX_NO_CROSS_BATCH=1
+export NTTX_DEBUG=1 NTTX_CHUNK_MIB=$1 NTTX_XCD_GROUP=16 NTTX_NO_CROSS_BATCH=1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$1 -- python3 bench.py --batch 512 --steps 2 --warmup 0 --kernel-reps 1 --no-cpu-baseline > $OUT/pmc.log 2>&1
 python3 - <<PY
 import csv, glob, collections
