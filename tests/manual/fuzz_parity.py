@@ -1,111 +1,13 @@
-"""Randomised parity sweep on a GPU box (not part of the test suite): random table kinds, sizes,
-batches and inputs -- residues, arbitrary u64 and edge values -- through the host entry points,
-the split transform and the negacyclic product, each compared with the CPU oracle.
-Usage: python tests/manual/fuzz_parity.py [seconds] [seed]"""
-import os, sys, time
+"""Randomised parity sweep on a GPU box for as long as asked (tests/_fuzz.py holds the cases; the
+test suite runs a bounded slice of it).  Usage: python tests/manual/fuzz_parity.py [seconds] [seed]"""
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np
-import ntt_amd
-import _oracle as orc
+import _fuzz  # noqa: E402
 
-Q61, R61 = 0x1FFFFFFFFFE00001, 0x0B4F9CB5C38B40B1
-QGL = 0xFFFFFFFF00000001
-Q32, R32 = 4293918721, 2004365341
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-tables = {}
-
-
-def get(kind, logn):
-    key = (kind, logn)
-    if key not in tables:
-        n = 1 << logn
-        if kind == "mont61":
-            psi = pow(R61, (1 << 20) // n, Q61)
-            tables[key] = (ntt_amd.Table.from_prime_and_root(Q61, psi, n), orc.Table.from_prime_and_root(Q61, psi, n), Q61)
-        elif kind == "mont32":
-            psi = pow(R32, (1 << 16) // n, Q32)
-            tables[key] = (ntt_amd.Table.from_prime_and_root(Q32, psi, n), orc.Table.from_prime_and_root(Q32, psi, n), Q32)
-        else:
-            psi = pow(7, (QGL - 1) // (2 * n), QGL)
-            if kind == "montwide":
-                tables[key] = (ntt_amd.Table.from_prime_and_root(QGL, psi, n), orc.Table.from_prime_and_root(QGL, psi, n), QGL)
-            else:
-                tables[key] = (ntt_amd.TableGoldilock.from_root(psi, n), orc.TableGoldilock.from_root(psi, n), QGL)
-    return tables[key]
-
-
-def inputs(q, count, style):
-    if style == 0:
-        return rng.integers(0, q, count, dtype=np.uint64)
-    if style == 1:
-        return rng.integers(0, 2**64, count, dtype=np.uint64)
-    if style == 3:     # lazily reduced: residue + a small multiple of q (wraps past 2^64 for 64-bit q)
-        a = rng.integers(0, q, count, dtype=np.uint64) + np.uint64(q) * rng.integers(0, 8, count, dtype=np.uint64)
-        near = rng.random(count) < 0.05
-        a[near] = (np.uint64(q) * rng.integers(1, 9, int(near.sum()), dtype=np.uint64)
-                   + rng.integers(0, 3, int(near.sum()), dtype=np.uint64) - np.uint64(1))
-        return a
-    a = rng.integers(0, q, count, dtype=np.uint64)
-    edges = np.array([0, 1, q - 1, q, (q + 1) % 2**64, 2**64 - 1, 2**32 - 1, 2**32, q - 2, 4 * q % 2**64, 2**63],
-                     dtype=np.uint64)
-    pick = rng.random(count) < 0.3
-    a[pick] = edges[rng.integers(0, len(edges), int(pick.sum()))]
-    return a
-
-
-t_end = time.time() + budget
-cases = 0
-last = time.time()
-while time.time() < t_end:
-    kind = ["mont61", "mont32", "montwide", "goldilocks"][rng.integers(0, 4)]
-    logn = int(rng.choice([2, 4, 6, 8, 10, 12, 14, 16] if kind == "mont32" else [2, 4, 6, 8, 10, 12, 14, 16, 18, 20]))
-    n = 1 << logn
-    batch = int(rng.integers(1, 70 if logn <= 14 else (24 if logn <= 16 else 3)))
-    gpu, ref, q = get(kind, logn)
-    mode = int(rng.integers(0, 4))
-    style = int(rng.integers(0, 4))
-    a = inputs(q, n * batch, style)
-    tag = (kind, logn, batch, mode, style)
-    if mode == 0:      # forward
-        w = a.copy()
-        for b in range(batch):
-            ref.forward_inplace(w[b * n:(b + 1) * n])
-        gpu.forward_inplace_batch(a, batch)
-        assert np.array_equal(a, w), tag
-    elif mode == 1:    # backward
-        w = a.copy()
-        for b in range(batch):
-            ref.backward_inplace(w[b * n:(b + 1) * n])
-        gpu.backward_inplace_batch(a, batch)
-        assert np.array_equal(a, w), tag
-    elif mode == 2 and logn >= 16:   # split transform of one vector
-        f = logn % 8 or 8
-        shards = int(rng.choice([s for s in (1, 2, 4, 8, 16) if s <= (1 << f) and logn >= f + s.bit_length() - 1 + 4]))
-        x, w = a[:n].copy(), a[:n].copy()
-        fwd = bool(rng.integers(0, 2))
-        (ref.forward_inplace if fwd else ref.backward_inplace)(w)
-        (gpu.forward_inplace_distributed if fwd else gpu.backward_inplace_distributed)(x, shards)
-        assert np.array_equal(x, w), tag + (shards, fwd)
-    else:              # negacyclic product of residues
-        a = inputs(q, n * batch, 0)
-        b2 = inputs(q, n * batch, 0)
-        want = a.copy()
-        for b in range(batch):
-            fa, fb = a[b * n:(b + 1) * n].copy(), b2[b * n:(b + 1) * n].copy()
-            ref.forward_inplace(fa)
-            ref.forward_inplace(fb)
-            prod = np.array([int(x) * int(y) % q for x, y in zip(fa, fb)], dtype=np.uint64) if n <= 4096 else None
-            if prod is None:   # big products with Python ints are slow: object arrays
-                prod = (fa.astype(object) * fb.astype(object) % q).astype(np.uint64)
-            ref.backward_inplace(prod)
-            want[b * n:(b + 1) * n] = prod
-        gpu.negacyclic_mul_inplace(a, b2)
-        assert np.array_equal(a, want), tag
-    cases += 1
-    if time.time() - last > 20:
-        last = time.time()
-        print("fuzz: %d cases so far, last %s" % (cases, tag), flush=True)
-print("fuzz: %d random cases passed in %.0f s" % (cases, budget))
+cases, seen = _fuzz.run(budget, int(sys.argv[2]) if len(sys.argv) > 2 else 1, progress=True)
+print("fuzz: %d random cases passed in %.0f s (%s)" % (cases, budget, ", ".join(sorted(seen))))
