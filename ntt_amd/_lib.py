@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnttx.so")
+# NTTX_LIB_PATH: another build of the same library (kernel experiments); never a different implementation
+LIB_PATH = os.environ.get("NTTX_LIB_PATH") or os.path.join(_HERE, "libnttx.so")
 
 NTTX_OK, NTTX_EINVAL, NTTX_ENODEV, NTTX_ENOMEM, NTTX_EHIP = range(5)
 NTTX_MONT64, NTTX_GOLDILOCKS = 0, 1

@@ -43,7 +43,9 @@ enum : uint32_t {
     PASS_CROSS_BATCH = 128u,   // CONTIG 8-stage pass: a tile is the same 256-element block of 16 consecutive transforms
     PASS_POINTWISE = 256u,     // first pass of a backward transform: multiply by the vector at data2 first
     PASS_OFFSET32 = 512u,      // every element of a tile lies within 2^31 bytes of the tile's first: buffer addressing
-    PASS_LAZY = 1024u          // outputs of the transform in the policy's lazy range ([0, 2q)) instead of canonical
+    PASS_LAZY = 1024u,         // outputs of the transform in the policy's lazy range ([0, 2q)) instead of canonical
+    PASS_DEBUG_HOT_TILES = 2048u // profiling aid (NTTX_DEBUG_HOT_TILES=1): every workgroup works on one of the first 64
+                               // tiles, so all traffic is served by the L2s -- the pass time with HBM out of the picture
 };
 // radix()'s `scale` argument
 enum : int { SCALE_NONE = 0, SCALE_CANONICAL = 1, SCALE_LAZY = 2 };
@@ -320,6 +322,17 @@ struct TileGeom {
 // Buffer addressing (scalar resource + 32-bit lane offset + scalar offset): the address of an
 // element costs no vector arithmetic.  The resource starts at a tile's first element and spans
 // 4 GiB, so the range check never fires; callers keep every offset inside the allocation.
+// Cache policy of the data loads / stores (the `aux` operand of the buffer instructions on gfx950:
+// 1 = sc0, 2 = nt, 16 = sc1, 0 = default policy).  A pass reads every element once and writes it
+// once, so both are non-temporal.  A/B on the headline workload: default / nt loads / nt stores / both
+// = 1.183 / 1.195 / 1.184 / 1.218 M pairs/s on one box (sc1 loads: 1.182), no difference on another;
+// Goldilocks 2^16 and 2^20 gain 2 % there.  Twiddles are read through ordinary loads and stay cached.
+#ifndef NTTX_LOAD_AUX
+#define NTTX_LOAD_AUX 2
+#endif
+#ifndef NTTX_STORE_AUX
+#define NTTX_STORE_AUX 2
+#endif
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_resource(const uint64_t* first)
@@ -328,25 +341,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_resource(const uint64_t* 
 }
 __device__ __forceinline__ uint64_t buffer_load64(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes)
 {
-    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, uniform_bytes, 0);
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, uniform_bytes, NTTX_LOAD_AUX);
     return pack64(v.x, v.y);
 }
 __device__ __forceinline__ ulonglong2 buffer_load128(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes)
 {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, uniform_bytes, 0);
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, uniform_bytes, NTTX_LOAD_AUX);
     return make_ulonglong2(pack64(v.x, v.y), pack64(v.z, v.w));
 }
 __device__ __forceinline__ void buffer_store128(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes,
                                                 ulonglong2 x)
 {
     const u32x4_t v = {lo32(x.x), hi32(x.x), lo32(x.y), hi32(x.y)};
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, lane_bytes, uniform_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, lane_bytes, uniform_bytes, NTTX_STORE_AUX);
 }
 __device__ __forceinline__ void buffer_store64(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes,
                                                uint64_t x)
 {
     const u32x2_t v = {lo32(x), hi32(x)};
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, lane_bytes, uniform_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, lane_bytes, uniform_bytes, NTTX_STORE_AUX);
 }
 
 // Tests a pass flag through an opaque scalar copy: the compiler then cannot tell that two tests
@@ -802,6 +815,8 @@ __global__ __launch_bounds__(THREADS, 4) void pass_kernel(PassParams p, typename
         const uint32_t G = p.xcd_group;
         tile = ((uint64_t)(blockIdx.x / (8 * G)) * 8 + blockIdx.x % 8) * G + (blockIdx.x / 8) % G;
     }
+    if (p.flags & PASS_DEBUG_HOT_TILES)
+        tile &= 63;
     const TileGeom<K, XB> g(p, tile);
 
     if constexpr (K1 == 4 && K2 == 4) {

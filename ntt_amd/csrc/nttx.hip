@@ -262,6 +262,8 @@ int device_slot(const nttx_plan* plan, int device)
 //   NTTX_DEBUG_NO_MATH=1|A|B   skip the butterflies (of one register round), keep all traffic
 //   NTTX_DEBUG_NO_TW=1         with NO_MATH: skip the twiddle loads too
 //   NTTX_DEBUG_NO_FINISH=1     skip the canonicalising end of the forward transform
+//   NTTX_DEBUG_HOT_TILES=1     every workgroup works on one of the first 64 tiles (all traffic from L2;
+//                              results are meaningless): the pass time with HBM out of the picture
 //   NTTX_XCD_GROUP=<G>         runs of G tiles per XCD on every pass (0 = plain order)
 //   NTTX_CHUNK_MIB=<m>         all passes over m MiB of the batch before the next m MiB
 // (NTTX_DEBUG_EXTRA_LDS is read next to the launches, in launch_impl.hpp.)
@@ -283,6 +285,8 @@ const Switches& switches()
                                                                                         : (uint32_t)PASS_DEBUG_NO_MATH;
         if (std::getenv("NTTX_DEBUG_NO_TW"))
             s.debug_flags |= PASS_DEBUG_NO_TW;
+        if (std::getenv("NTTX_DEBUG_HOT_TILES"))
+            s.debug_flags |= PASS_DEBUG_HOT_TILES;
         s.no_finish = std::getenv("NTTX_DEBUG_NO_FINISH") != nullptr;
         if (const char* e = std::getenv("NTTX_XCD_GROUP"))
             s.xcd_group = std::atol(e);

@@ -4,7 +4,7 @@
 WL=$1; shift
 for e in "$@"; do
   [ "$e" = "-" ] && e="NTTX_NONE=1"
-  env $e timeout -k 10 120 python3 bench.py --workload $WL --no-cpu-baseline --steps 30 2>/dev/null | python3 -c "
+  env $e timeout -k 10 120 python3 bench.py --workload $WL --no-cpu-baseline --no-verify --steps 30 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 print('%-40s %10.1f pairs/s  %.4f ms/step  ' % ('$e', d['value'], d['ms_per_step']) + '  '.join('%s %.3f' % (k['name'].split(' stages')[0], k['avg_ms']) for k in d['roofline']['kernels']))
