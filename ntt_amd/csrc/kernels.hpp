@@ -44,6 +44,9 @@ enum : uint32_t {
     PASS_POINTWISE = 256u,     // first pass of a backward transform: multiply by the vector at data2 first
     PASS_OFFSET32 = 512u,      // every element of a tile lies within 2^31 bytes of the tile's first: buffer addressing
     PASS_LAZY = 1024u,         // outputs of the transform in the policy's lazy range ([0, 2q)) instead of canonical
+    PASS_COHERENT_LOADS = 4096u, // data loads bypass the CU's vector L1 (sc1): the tile was written by other
+                               // workgroups of the same launch on the same XCD (fused16_kernel)
+    PASS_CACHED_STORES = 8192u,  // data stores with the default cache policy: the tile is re-read from L2 soon
     PASS_DEBUG_HOT_TILES = 2048u // profiling aid (NTTX_DEBUG_HOT_TILES=1): every workgroup works on one of the first 64
                                // tiles, so all traffic is served by the L2s -- the pass time with HBM out of the picture
 };
@@ -339,28 +342,33 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_resource(const uint64_t* 
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(first), 0, 0xffffffff, 0x00020000);
 }
+template <int AUX = NTTX_LOAD_AUX>
 __device__ __forceinline__ uint64_t buffer_load64(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes)
 {
-    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, uniform_bytes, NTTX_LOAD_AUX);
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, uniform_bytes, AUX);
     return pack64(v.x, v.y);
 }
+template <int AUX = NTTX_LOAD_AUX>
 __device__ __forceinline__ ulonglong2 buffer_load128(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes)
 {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, uniform_bytes, NTTX_LOAD_AUX);
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, uniform_bytes, AUX);
     return make_ulonglong2(pack64(v.x, v.y), pack64(v.z, v.w));
 }
+template <int AUX = NTTX_STORE_AUX>
 __device__ __forceinline__ void buffer_store128(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes,
                                                 ulonglong2 x)
 {
     const u32x4_t v = {lo32(x.x), hi32(x.x), lo32(x.y), hi32(x.y)};
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, lane_bytes, uniform_bytes, NTTX_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, lane_bytes, uniform_bytes, AUX);
 }
+template <int AUX = NTTX_STORE_AUX>
 __device__ __forceinline__ void buffer_store64(__amdgpu_buffer_rsrc_t r, uint32_t lane_bytes, uint32_t uniform_bytes,
                                                uint64_t x)
 {
     const u32x2_t v = {lo32(x), hi32(x)};
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, lane_bytes, uniform_bytes, NTTX_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, lane_bytes, uniform_bytes, AUX);
 }
+constexpr int AUX_SC1 = 16; // agent scope: served by the XCD's L2, never by this CU's L1
 
 // Tests a pass flag through an opaque scalar copy: the compiler then cannot tell that two tests
 // of the same flag agree, and does not clone everything between them for each outcome.
@@ -421,9 +429,19 @@ struct Round {
             const __amdgpu_buffer_rsrc_t res = tile_resource(p.data + g.uniform_index());
             const uint32_t lane = (uint32_t)g.lane_index(ss, r0) * 8u;
             const uint32_t stepb = 8u << (g.logT + rstep_log);
+            if (flag_set(p.flags, PASS_COHERENT_LOADS)) {
 #pragma unroll
-            for (int i = 0; i < M; i++)
-                x[i] = buffer_load64(res, lane, i * stepb);
+                for (int i = 0; i < M; i++)
+                    x[i] = buffer_load64<AUX_SC1>(res, lane, i * stepb);
+            } else if (flag_set(p.flags, PASS_CACHED_STORES)) {
+#pragma unroll
+                for (int i = 0; i < M; i++)
+                    x[i] = buffer_load64<0>(res, lane, i * stepb);
+            } else {
+#pragma unroll
+                for (int i = 0; i < M; i++)
+                    x[i] = buffer_load64(res, lane, i * stepb);
+            }
         } else {
             const uint64_t* src = p.data + g.uniform_index() + g.lane_index(ss, r0);
             const uint64_t step = 1ull << (g.logT + rstep_log);
@@ -443,9 +461,15 @@ struct Round {
             const __amdgpu_buffer_rsrc_t res = tile_resource(p.data + g.uniform_index());
             const uint32_t lane = (uint32_t)g.lane_index(sigma, r0) * 8u;
             const uint32_t stepb = 8u << (g.logT + rstep_log);
+            if (flag_set(p.flags, PASS_CACHED_STORES)) {
 #pragma unroll
-            for (int i = 0; i < M; i++)
-                buffer_store64(res, lane, i * stepb, x[i]);
+                for (int i = 0; i < M; i++)
+                    buffer_store64<0>(res, lane, i * stepb, x[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < M; i++)
+                    buffer_store64(res, lane, i * stepb, x[i]);
+            }
         } else {
             uint64_t* dst = p.data + g.gidx(sigma, r0);
             const uint64_t step = 1ull << (g.logT + rstep_log);
@@ -570,10 +594,15 @@ __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<
     };
     auto present = [&](int i) -> bool { return XB ? (fu(i) >> K) < left : fu(i) + fl < left; };
     const bool buffers = flag_set(p.flags, PASS_OFFSET32);
+    const bool coherent = flag_set(p.flags, PASS_COHERENT_LOADS), cached = flag_set(p.flags, PASS_CACHED_STORES);
     auto load_pair = [&](const uint64_t* from, int i) -> ulonglong2 {
         ulonglong2 v = make_ulonglong2(0, 0);
         if (present(i)) {
-            if (buffers)
+            if (buffers && coherent)
+                v = buffer_load128<AUX_SC1>(tile_resource(from + first), fl * 8, (uint32_t)uniform_elems(i) * 8);
+            else if (buffers && cached)
+                v = buffer_load128<0>(tile_resource(from + first), fl * 8, (uint32_t)uniform_elems(i) * 8);
+            else if (buffers)
                 v = buffer_load128(tile_resource(from + first), fl * 8, (uint32_t)uniform_elems(i) * 8);
             else
                 v = *reinterpret_cast<const ulonglong2*>(from + first + uniform_elems(i) + fl);
@@ -617,7 +646,9 @@ __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<
                 ulonglong2 v;
                 v.x = at[0];
                 v.y = at[1];
-                if (buffers)
+                if (buffers && cached)
+                    buffer_store128<0>(tile_resource(p.data + first), fl * 8, (uint32_t)uniform_elems(i) * 8, v);
+                else if (buffers)
                     buffer_store128(tile_resource(p.data + first), fl * 8, (uint32_t)uniform_elems(i) * 8, v);
                 else
                     *reinterpret_cast<ulonglong2*>(p.data + first + uniform_elems(i) + fl) = v;
@@ -920,6 +951,169 @@ __global__ __launch_bounds__(THREADS, 4) void fused_small_kernel(PassParams p, t
             if (math)
                 radix<A, KF, false>(x, RegTw<A, KF>{w}, c, scale_mode(p.flags));
             r.store_global(x, pf, gf);
+        }
+    }
+}
+
+// ---- both passes of a 2^16-point transform in ONE launch ------------------------------------------
+//
+// The two 8-stage passes of n = 2^16 exchange their data through the XCD's L2 instead of HBM: a
+// transform is 16 tiles in either pass, the 16 workgroups that take them (a "team") all run on
+// one XCD, and the second pass of a transform starts as soon as the team's 16 first-pass tiles are
+// stored -- its loads then hit the lines the first pass left in that XCD's L2, and the second
+// pass's stores overwrite them before they are ever written back.  HBM sees one read and one write
+// of the batch per transform instead of two.
+//
+// Scheduling is by tickets, per XCD (the hardware's XCC_ID register, not an assumption about
+// dispatch order): ticket t of an XCD's first-phase counter is tile t mod 16 of that XCD's team
+// t / 16, and likewise for the second phase.  The holder of a team's first ticket claims the team's
+// transform from one global counter (in team order, so a team without a transform is never
+// followed by one with), which also balances the XCDs and makes every placement of workgroups
+// correct, including XCDs that receive none.  A workgroup never blocks before its first-phase tile
+// is stored, and while its second-phase tile waits for the team it takes further first-phase
+// tickets instead of spinning, so every wait ends for any number of resident workgroups.  Every
+// second-phase ticket is preceded by a first-phase ticket of the same workgroup, so the team a
+// second-phase ticket names has always been created.
+//
+// Visibility inside the XCD: first-phase stores use the default policy (they stay in L2); every
+// storing wave drains them (s_waitcnt vmcnt(0)) before the workgroup barrier that precedes the
+// arrival count; second-phase loads carry sc1 (served by L2: a CU's vector L1 is not refreshed by
+// other CUs' stores).  All tiles of a team are on one XCD, whose CUs share that L2.
+struct FusedSync {
+    // all fields are 32-bit counters in device memory, zeroed before each launch
+    uint32_t* ticket1;  // [8][32]: first-phase tickets per XCD (one counter per 128 bytes)
+    uint32_t* ticket2;  // [8][32]: second-phase tickets per XCD
+    uint32_t* next;     // transforms claimed so far
+    uint32_t* arrived;  // [batch]: first-phase tiles stored, per transform
+    uint32_t* team;     // [8][team_stride]: transform of each XCD's team + 1 (0 = not claimed yet)
+    uint32_t team_stride;
+    uint32_t batch;
+};
+
+__device__ __forceinline__ uint32_t relaxed_load(const uint32_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Polls until *p != 0.  Every such wait in fused16_kernel is for a running workgroup that does
+// not block before it writes *p; the bound only turns a bug into a trap instead of a hang.
+__device__ __forceinline__ uint32_t wait_nonzero(const uint32_t* p)
+{
+    for (uint32_t spins = 0;; spins++) {
+        const uint32_t v = relaxed_load(p);
+        if (v != 0)
+            return v;
+        __builtin_amdgcn_s_sleep(4);
+        if (spins > (1u << 24))
+            __builtin_trap();
+    }
+}
+
+template <class A, bool FWD>
+__global__ __launch_bounds__(THREADS, 2) void fused16_kernel(PassParams p1, PassParams p2, FusedSync y, typename A::Ctx c)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) typename A::TwElem ldstw[LDSTW_ELEMS];
+    __shared__ uint32_t mail[2];
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): id 20, offset 0, width 4
+    const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
+    uint32_t* const ticket1 = y.ticket1 + xcc * 32;
+    uint32_t* const ticket2 = y.ticket2 + xcc * 32;
+    uint32_t* const team = y.team + (uint64_t)xcc * y.team_stride;
+    const bool leader = threadIdx.x == 0;
+
+    // value computed by thread 0, handed to the whole workgroup
+    auto broadcast = [&](uint32_t v) -> uint32_t {
+        if (leader)
+            mail[0] = v;
+        __syncthreads();
+        const uint32_t r = mail[0];
+        __syncthreads();
+        return r;
+    };
+    // first-phase ticket -> (transform, tile); transform >= batch: the batch is used up
+    auto first_phase_work = [&](uint32_t& T, uint32_t& m) {
+        uint32_t v = 0, t = 0;
+        if (leader) {
+            t = atomicAdd(ticket1, 1u);
+            const uint32_t k = t >> 4;
+            if ((t & 15u) == 0) {
+                if (k > 0)
+                    (void)wait_nonzero(team + k - 1); // claims go in team order
+                const uint32_t claimed = atomicAdd(y.next, 1u);
+                v = (claimed < y.batch ? claimed : y.batch) + 1;
+                __hip_atomic_store(team + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                v = wait_nonzero(team + k);
+            }
+            mail[1] = t & 15u;
+        }
+        T = broadcast(v) - 1;
+        m = mail[1];
+    };
+
+    bool more_first = true, holding = false;
+    uint32_t T2 = 0, m2 = 0, idle = 0;
+    for (;;) {
+        // ---- a first-phase tile, unless a second-phase tile is ready or the batch is used up ----
+        bool ready = false;
+        if (holding) {
+            uint32_t r = 0;
+            if (leader) {
+                for (int spins = 0; spins < 64 && !r; spins++) {
+                    r = relaxed_load(y.arrived + T2) >= 16u;
+                    if (!r)
+                        __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            ready = broadcast(r) != 0;
+            // nothing left to do but wait for other workgroups' first-phase tiles, which are in
+            // progress; a bound turns a scheduling bug into a trap instead of a hang
+            if (!ready && !more_first && ++idle > (1u << 18))
+                __builtin_trap();
+        }
+        // Also taken, without work to do, before every second-phase ticket once the batch is used up:
+        // second-phase ticket t belongs to the team that first-phase ticket 16 (t >> 4) creates, so
+        // the first-phase counter has to stay ahead of the second-phase one.
+        if (!ready && (more_first || !holding)) {
+            uint32_t T1, m1;
+            first_phase_work(T1, m1);
+            if (T1 < y.batch) {
+                const uint64_t tile = (uint64_t)T1 * 16 + m1;
+                if (FWD)
+                    pass_8<A, true, false, false>(p1, TileGeom<8, false>(p1, tile), c, lds, ldstw);
+                else
+                    pass_8<A, false, true, false>(p1, TileGeom<8, false>(p1, tile), c, lds, ldstw);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores have reached L2
+                __syncthreads();
+                if (leader)
+                    atomicAdd(y.arrived + T1, 1u);
+            } else {
+                more_first = false;
+            }
+        }
+        // ---- a second-phase ticket ----
+        if (!holding) {
+            uint32_t v = 0;
+            if (leader) {
+                const uint32_t t = atomicAdd(ticket2, 1u);
+                v = wait_nonzero(team + (t >> 4)); // claimed by the holder of first-phase ticket 16 (t >> 4) <= t
+                mail[1] = t & 15u;
+            }
+            T2 = broadcast(v) - 1;
+            m2 = mail[1];
+            if (T2 >= y.batch)
+                break; // no transform left for this XCD's teams
+            holding = true;
+            continue;
+        }
+        if (ready) {
+            const uint64_t tile = (uint64_t)T2 * 16 + m2;
+            if (FWD)
+                pass_8<A, true, true, false>(p2, TileGeom<8, false>(p2, tile), c, lds, ldstw);
+            else
+                pass_8<A, false, false, false>(p2, TileGeom<8, false>(p2, tile), c, lds, ldstw);
+            __syncthreads();
+            holding = false;
         }
     }
 }

@@ -59,9 +59,23 @@ hipError_t launch_fused_policy(bool fwd, int kf, const PassParams& p, const type
     return hipGetLastError();
 }
 
+template <class A>
+hipError_t launch_fused16_policy(bool fwd, const PassParams& p1, const PassParams& p2, const FusedSync& y,
+                                 const typename A::Ctx& c, unsigned grid, hipStream_t s)
+{
+    (void)hipGetLastError();
+    if (fwd)
+        hipLaunchKernelGGL((fused16_kernel<A, true>), dim3(grid), dim3(THREADS), 0, s, p1, p2, y, c);
+    else
+        hipLaunchKernelGGL((fused16_kernel<A, false>), dim3(grid), dim3(THREADS), 0, s, p1, p2, y, c);
+    return hipGetLastError();
+}
+
 #define NTTX_INSTANTIATE_POLICY(A)                                                                                   \
     template hipError_t launch_pass_policy<A>(bool, const PassDesc&, const PassParams&, const A::Ctx&, unsigned,      \
                                               hipStream_t);                                                          \
-    template hipError_t launch_fused_policy<A>(bool, int, const PassParams&, const A::Ctx&, unsigned, hipStream_t);
+    template hipError_t launch_fused_policy<A>(bool, int, const PassParams&, const A::Ctx&, unsigned, hipStream_t);   \
+    template hipError_t launch_fused16_policy<A>(bool, const PassParams&, const PassParams&, const FusedSync&,        \
+                                                 const A::Ctx&, unsigned, hipStream_t);
 
 } // namespace nttx

@@ -194,6 +194,19 @@ struct nttx_plan {
         std::unique_ptr<CopyPool> pool;
     };
     mutable std::vector<std::unique_ptr<HostSlot>> host_slots;
+    // Counters of the one-launch n = 2^16 transform (fused16_kernel), per device: a few sets, used in
+    // turn, each guarded by an event so that a set is zeroed for a new launch only after the launch
+    // that used it last has finished (launches of one plan may be in flight on several streams).
+    struct FusedSlot {
+        static constexpr int SETS = 4;
+        std::mutex lock;
+        uint32_t* sets[SETS] = {};
+        hipEvent_t done[SETS] = {};
+        bool used[SETS] = {};
+        unsigned next = 0;
+        int cus = 0; // compute units of the device
+    };
+    mutable std::vector<std::unique_ptr<FusedSlot>> fused_slots;
 };
 
 namespace {
@@ -403,6 +416,98 @@ int launch_fused(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, 
     return NTTX_OK;
 }
 
+uint32_t pass_flags(const PassDesc& d, size_t fi, size_t np, bool fwd);
+
+// ---- n = 2^16 in one launch (fused16_kernel) -----------------------------------------------------
+// Largest batch of one fused launch (the counters are sized for it) and the smallest worth one.
+constexpr size_t FUSED16_MAX_BATCH = 1u << 16;
+constexpr size_t FUSED16_MIN_BATCH = 64;
+constexpr unsigned FUSED16_WGS_PER_CU = 2;
+// 32-bit words of one counter set: two ticket arrays, the claim counter, arrivals, teams per XCD
+size_t fused16_words(size_t batch, unsigned grid, uint32_t* team_stride)
+{
+    // teams per XCD: at most one per transform, plus the empty ones created while the batch runs out
+    // (at most two first-phase tickets per workgroup)
+    *team_stride = (uint32_t)(batch + grid / 4 + 16);
+    return 256 + 256 + 32 + batch + 8ull * *team_stride;
+}
+
+bool fused16_applies(const nttx_plan* plan, size_t batch)
+{
+    // Opt-in (NTTX_FUSED16=1).  Measured on MI355X, batch 4096: the second pass's loads do hit L2
+    // (FETCH_SIZE x 2 = 2.17 GB per transform of the batch instead of 4.3 GB) but the L2 writes
+    // through (WRITE_SIZE stays 4.1 GB), and with 178 VGPRs only two workgroups fit a CU, which
+    // cannot hide a tile's latency: 3.7-3.9 ms per direction against 1.6-1.7 ms for the two launches.
+    static const int mode = [] {
+        const char* e = std::getenv("NTTX_FUSED16");
+        return e ? std::atoi(e) : 0;
+    }();
+    return mode != 0 && plan->logn == 16 && batch >= FUSED16_MIN_BATCH && batch <= FUSED16_MAX_BATCH &&
+           !plan->fused_slots.empty();
+}
+
+int launch_fused16(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream, bool lazy)
+{
+    nttx_plan::FusedSlot& fs = *plan->fused_slots[(size_t)slot];
+    const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)fs.cus * FUSED16_WGS_PER_CU, (uint64_t)batch * 16);
+    uint32_t team_stride = 0;
+    const size_t words = fused16_words(batch, grid, &team_stride);
+    // passes in forward order: [0] strided stages 1-8, [1] contiguous stages 9-16
+    const PassDesc& strided = plan->split_passes[0];
+    const PassDesc& contig = plan->split_passes[1];
+    auto params = [&](const PassDesc& d, size_t fi) {
+        PassParams p{};
+        p.data = dptr;
+        p.tw = fwd ? plan->d_fwd[slot] : plan->d_inv[slot];
+        p.tw_perm = fwd ? plan->d_fwd_perm[slot] : plan->d_inv_perm[slot];
+        p.nblocks_total = (uint64_t)batch << d.s0;
+        p.block_base = 0;
+        p.logB = plan->logn - d.s0;
+        p.s0 = d.s0;
+        p.flags = pass_flags(d, fi, 2, fwd) | (lazy ? (uint32_t)PASS_LAZY : 0u);
+        if (!switches().no_buffer)
+            p.flags |= PASS_OFFSET32;
+        apply_debug_flags(p);
+        return p;
+    };
+    PassParams ps = params(strided, 0), pc = params(contig, 1);
+    PassParams& p1 = fwd ? ps : pc;
+    PassParams& p2 = fwd ? pc : ps;
+    p1.flags |= PASS_CACHED_STORES;
+    p2.flags |= PASS_COHERENT_LOADS;
+
+    std::lock_guard<std::mutex> guard(fs.lock);
+    const unsigned set = fs.next++ % nttx_plan::FusedSlot::SETS;
+    if (fs.used[set])
+        HIP_TRY(hipStreamWaitEvent(stream, fs.done[set], 0)); // the launch that used this set last
+    uint32_t* w = fs.sets[set];
+    HIP_TRY(hipMemsetAsync(w, 0, words * sizeof(uint32_t), stream));
+    FusedSync y{};
+    y.ticket1 = w;
+    y.ticket2 = w + 256;
+    y.next = w + 512;
+    y.arrived = w + 544;
+    y.team = w + 544 + batch;
+    y.team_stride = team_stride;
+    y.batch = (uint32_t)batch;
+    hipError_t e;
+    switch (plan->policy) {
+    case nttx_plan::GOLDILOCKS: e = launch_fused16_policy<Goldilocks>(fwd, p1, p2, y, plan->gctx, grid, stream); break;
+    case nttx_plan::GOLDILOCKS_CANONICAL:
+        e = launch_fused16_policy<GoldilocksCanonical>(fwd, p1, p2, y, plan->gctx, grid, stream);
+        break;
+    case nttx_plan::MONT_WIDE: e = launch_fused16_policy<Mont<true>>(fwd, p1, p2, y, plan->mctx, grid, stream); break;
+    case nttx_plan::MONT: e = launch_fused16_policy<Mont<false>>(fwd, p1, p2, y, plan->mctx, grid, stream); break;
+    case nttx_plan::SHOUP61_NEAR: e = launch_fused16_policy<Shoup61Near>(fwd, p1, p2, y, plan->sctx, grid, stream); break;
+    default: e = launch_fused16_policy<Shoup61>(fwd, p1, p2, y, plan->sctx, grid, stream); break;
+    }
+    if (e != hipSuccess)
+        return fail(NTTX_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(fs.done[set], stream));
+    fs.used[set] = true;
+    return NTTX_OK;
+}
+
 // Flags of the pass at forward-order position `fi` of `np` when running direction `fwd`.
 uint32_t pass_flags(const PassDesc& d, size_t fi, size_t np, bool fwd)
 {
@@ -425,6 +530,8 @@ int enqueue_passes(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch
                    int only_pass, const uint64_t* mul_with, bool lazy)
 {
     static const bool no_xb = std::getenv("NTTX_NO_CROSS_BATCH") != nullptr;
+    if (only_pass < 0 && mul_with == nullptr && fused16_applies(plan, batch))
+        return launch_fused16(plan, slot, dptr, batch, fwd, stream, lazy);
     const size_t np = plan->passes.size();
     for (size_t i = 0; i < np; i++) {
         if (only_pass >= 0 && (size_t)only_pass != i)
@@ -1055,8 +1162,24 @@ int finish_plan(nttx_plan* plan, const TableSource& src, const int* devices, int
     plan->d_inv.assign(nd, nullptr);
     plan->d_fwd_perm.assign(nd, nullptr);
     plan->d_inv_perm.assign(nd, nullptr);
+    plan->fused_slots.clear();
+    if (plan->logn == 16)
+        for (size_t i = 0; i < nd; i++)
+            plan->fused_slots.emplace_back(new nttx_plan::FusedSlot);
     for (size_t i = 0; i < nd; i++) {
         HIP_TRY(hipSetDevice(plan->devices[i]));
+        if (plan->logn == 16) {
+            nttx_plan::FusedSlot& fs = *plan->fused_slots[i];
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, plan->devices[i]));
+            fs.cus = prop.multiProcessorCount;
+            uint32_t stride = 0;
+            const size_t words = fused16_words(FUSED16_MAX_BATCH, (unsigned)fs.cus * FUSED16_WGS_PER_CU, &stride);
+            for (int k = 0; k < nttx_plan::FusedSlot::SETS; k++) {
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&fs.sets[k]), words * sizeof(uint32_t)));
+                HIP_TRY(hipEventCreateWithFlags(&fs.done[k], hipEventDisableTiming));
+            }
+        }
         HIP_TRY(hipMalloc(&plan->d_fwd_perm[i], bytes));
         HIP_TRY(hipMalloc(&plan->d_inv_perm[i], bytes));
         for (int dir = 0; dir < 2; dir++) {
@@ -1389,6 +1512,14 @@ void nttx_plan_destroy(nttx_plan* plan)
             (void)hipFree(plan->d_fwd_perm[i]);
         if (i < plan->d_inv_perm.size() && plan->d_inv_perm[i])
             (void)hipFree(plan->d_inv_perm[i]);
+        if (i < plan->fused_slots.size() && plan->fused_slots[i]) {
+            for (int k = 0; k < nttx_plan::FusedSlot::SETS; k++) {
+                if (plan->fused_slots[i]->sets[k])
+                    (void)hipFree(plan->fused_slots[i]->sets[k]);
+                if (plan->fused_slots[i]->done[k])
+                    (void)hipEventDestroy(plan->fused_slots[i]->done[k]);
+            }
+        }
         if (i < plan->host_slots.size() && plan->host_slots[i]) {
             if (plan->host_slots[i]->stream)
                 (void)hipStreamDestroy(plan->host_slots[i]->stream);
