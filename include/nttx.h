@@ -159,12 +159,14 @@ int nttx_backward_device_lazy(const nttx_plan *plan, int device, void *dptr, siz
  * composition its callers write around the transforms -- forward_inplace(a), forward_inplace(b)
  * (ntt.rs:27-29 / ntt_goldilock.rs:21-23), coefficient-wise product mod q, backward_inplace
  * (ntt.rs:41-43 / ntt_goldilock.rs:35-37) -- with the product fused into the first pass of the
- * backward transform, so it costs no pass over memory of its own.  The coefficient-wise product
- * is the canonical residue (for NTTX_GOLDILOCKS: mul_reduce, ntt_goldilock.rs:183-190, which is
- * canonical even for the value q the forward transform can emit), so the result equals that
- * composition bit for bit.  Afterwards b holds its forward transform (device entry point; the
- * host entry point leaves the caller's b untouched).  Passing the same pointer as a and b
- * squares; partially overlapping operands are rejected (both entry points).
+ * backward transform, so it costs no pass over memory of its own; where the last forward pass and
+ * the first backward pass work on the same tiles (log2 n a multiple of 8, 16 pairs or more) those
+ * two passes of a, the last pass of b and the product are one launch.  The coefficient-wise
+ * product is the canonical residue (for NTTX_GOLDILOCKS: mul_reduce, ntt_goldilock.rs:183-190,
+ * which is canonical even for the value q the forward transform can emit), so the result equals
+ * that composition bit for bit.  The device entry point uses b as scratch: its contents afterwards
+ * are unspecified (the host entry point leaves the caller's b untouched).  Passing the same
+ * pointer as a and b squares; partially overlapping operands are rejected (both entry points).
  */
 int nttx_negacyclic_mul_host(const nttx_plan *plan, uint64_t *a, const uint64_t *b, size_t batch);
 int nttx_negacyclic_mul_device(const nttx_plan *plan, int device, void *a, void *b, size_t batch,

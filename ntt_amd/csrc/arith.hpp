@@ -374,8 +374,9 @@ struct Shoup61T {
         return (x >= c.q) ? canon4(mul(x, make(c.one), c), c) : x;
     }
 
-    // a * b * 2^-64 mod q in [0, q) for residues a, b (neither has a precomputed quotient, so this
-    // is REDC as in utils.rs:165-178); the plan folds the factor 2^64 back in with n^-1.
+    // a * b * 2^-64 mod q in [0, q) for a, b in [0, 2q) (neither has a precomputed quotient, so this
+    // is REDC as in utils.rs:165-178: hi(a * b) < 4 q^2 / 2^64 < q keeps the result canonical); the
+    // plan folds the factor 2^64 back in with n^-1.
     static NTTX_HD uint64_t pointwise(uint64_t a, uint64_t b, const Ctx& c)
     {
         uint64_t hi, lo;

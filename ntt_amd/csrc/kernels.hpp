@@ -955,6 +955,105 @@ __global__ __launch_bounds__(THREADS, 4) void fused_small_kernel(PassParams p, t
     }
 }
 
+// ---- the middle of a negacyclic product in ONE launch ----------------------------------------------
+//
+// a <- a * b in Z_q[X]/(X^n + 1) is forward(a), forward(b), the coefficient-wise product and one
+// backward transform.  The last forward pass and the first backward pass are both the 8-stage CONTIG
+// pass on the same tiles, and a thread ends the former holding exactly the 16 elements it needs to
+// begin the latter (the layout of round B).  So for cross-batch tiles this kernel runs, per tile:
+// the last forward pass of a, the last forward pass of b, the product in registers, and the first
+// backward pass, storing to a.  HBM sees two reads and one write of the tile instead of the five
+// reads and three writes of three separate launches; b is only read (it is left holding the output
+// of its earlier forward passes).  pf: the forward pass (data = a, data2 = b, forward twiddles,
+// PASS_FINISH); pb: the backward pass (data = a, backward twiddles).  data2 == data squares.
+//
+// Both operands' registers are live at once, so three workgroups fit a CU instead of four.
+template <class A>
+__global__ __launch_bounds__(THREADS, 3) void product_mid_kernel(PassParams pf, PassParams pb, typename A::Ctx c)
+{
+    __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) typename A::TwElem ldstw_f[LDSTW_ELEMS];
+    __shared__ __attribute__((aligned(16))) typename A::TwElem ldstw_b[LDSTW_ELEMS];
+    using RA = Round<A, true, 4, 4, true, true>;
+    using RB = Round<A, true, 4, 4, false, true>;
+    using TwElem = typename A::TwElem;
+    using Raw = __attribute__((ext_vector_type(sizeof(TwElem) / 4))) uint32_t;
+    uint64_t tile = blockIdx.x;
+    if (pf.flags & PASS_DEBUG_HOT_TILES)
+        tile &= 63;
+    const TileGeom<8, true> g(pf, tile);
+    const RA ra(g, 0);
+    const RB rb(g, 0);
+    const bool square = pf.data2 == pf.data;
+    const bool math = !(pf.flags & PASS_DEBUG_NO_MATH);
+
+    // twiddles of both directions, staged as pass_8 stages those of one: thread t fetches entry
+    // j = t & 15 of round B's set t >> 4; threads 0..15 also fetch round A's single set
+    const uint32_t set = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const uint32_t u = 32 - __clz(j | 1);
+    const uint32_t b = j ? j - (1u << (u - 1)) : 0;
+    const uint64_t at_b = (((g.twiddle_base(0) << 4) + set) << (u - 1)) + b;
+    const uint64_t at_a = (g.twiddle_base(0) << (u - 1)) + b;
+    const TwElem* twf = static_cast<const TwElem*>(pf.tw);
+    const TwElem* twb = static_cast<const TwElem*>(pb.tw);
+    const Raw mine_f = *reinterpret_cast<const Raw*>(twf + at_b), uni_f = *reinterpret_cast<const Raw*>(twf + at_a);
+    const Raw mine_b = *reinterpret_cast<const Raw*>(twb + at_b), uni_b = *reinterpret_cast<const Raw*>(twb + at_a);
+
+    // both operands' tiles are requested up front: the barrier below drains outstanding loads anyway
+    uint64_t xa[16], xb[16];
+    ra.load_global(xa, pf, g, c);
+    if (!square) {
+        PassParams p2 = pf;
+        p2.data = const_cast<uint64_t*>(pf.data2);
+        ra.load_global(xb, p2, g, c);
+    }
+    reinterpret_cast<Raw*>(ldstw_f)[set * TW_SET_STRIDE + j] = mine_f;
+    reinterpret_cast<Raw*>(ldstw_b)[set * TW_SET_STRIDE + j] = mine_b;
+    if (threadIdx.x < 16) {
+        reinterpret_cast<Raw*>(ldstw_f + 16 * TW_SET_STRIDE)[threadIdx.x] = uni_f;
+        reinterpret_cast<Raw*>(ldstw_b + 16 * TW_SET_STRIDE)[threadIdx.x] = uni_b;
+    }
+    const uint32_t own = (threadIdx.x & 15) * TW_SET_STRIDE;
+    const LdsTw<A> fa{ldstw_f + 16 * TW_SET_STRIDE, c}, fb{ldstw_f + own, c};
+    const LdsTw<A> ba{ldstw_b + 16 * TW_SET_STRIDE, c}, bb{ldstw_b + own, c};
+    __syncthreads();
+
+    if (math)
+        radix<A, 4, true>(xa, fa, c, SCALE_NONE);
+    ra.store_lds(xa, lds);
+    __syncthreads();
+    rb.load_lds(xa, lds);
+    if (math)
+        radix<A, 4, true>(xa, fb, c, SCALE_NONE);
+    finish_all<A, 16>(xa, c, pf.flags);
+    if (!square) {
+        if (math)
+            radix<A, 4, true>(xb, fa, c, SCALE_NONE);
+        __syncthreads(); // every thread has taken a's elements out of the tile
+        ra.store_lds(xb, lds);
+        __syncthreads();
+        rb.load_lds(xb, lds);
+        if (math)
+            radix<A, 4, true>(xb, fb, c, SCALE_NONE);
+        finish_all<A, 16>(xb, c, pf.flags);
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            xa[i] = A::pointwise(xa[i], xb[i], c);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            xa[i] = A::pointwise(xa[i], xa[i], c);
+    }
+    if (math)
+        radix<A, 4, false>(xa, bb, c, SCALE_NONE);
+    rb.store_lds(xa, lds); // the positions this thread read last: no other thread touches them
+    __syncthreads();
+    ra.load_lds(xa, lds);
+    if (math)
+        radix<A, 4, false>(xa, ba, c, scale_mode(pb.flags));
+    ra.store_global(xa, pb, g);
+}
+
 // ---- both passes of a 2^16-point transform in ONE launch ------------------------------------------
 //
 // The two 8-stage passes of n = 2^16 exchange their data through the XCD's L2 instead of HBM: a

@@ -71,11 +71,22 @@ hipError_t launch_fused16_policy(bool fwd, const PassParams& p1, const PassParam
     return hipGetLastError();
 }
 
+template <class A>
+hipError_t launch_product_mid_policy(const PassParams& pf, const PassParams& pb, const typename A::Ctx& c, unsigned grid,
+                                     hipStream_t s)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((product_mid_kernel<A>), dim3(grid), dim3(THREADS), 0, s, pf, pb, c);
+    return hipGetLastError();
+}
+
 #define NTTX_INSTANTIATE_POLICY(A)                                                                                   \
     template hipError_t launch_pass_policy<A>(bool, const PassDesc&, const PassParams&, const A::Ctx&, unsigned,      \
                                               hipStream_t);                                                          \
     template hipError_t launch_fused_policy<A>(bool, int, const PassParams&, const A::Ctx&, unsigned, hipStream_t);   \
     template hipError_t launch_fused16_policy<A>(bool, const PassParams&, const PassParams&, const FusedSync&,        \
-                                                 const A::Ctx&, unsigned, hipStream_t);
+                                                 const A::Ctx&, unsigned, hipStream_t);                               \
+    template hipError_t launch_product_mid_policy<A>(const PassParams&, const PassParams&, const A::Ctx&, unsigned,   \
+                                                     hipStream_t);
 
 } // namespace nttx

@@ -817,16 +817,106 @@ int enqueue(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool 
     return NTTX_OK;
 }
 
+// Whether the product of `batch` pairs takes product_mid_kernel for its cross-batch part: the last
+// forward pass is the 8-stage CONTIG pass of a longer transform (log2 n = 16, 24, ...).
+// NTTX_NO_PRODUCT_FUSION=1 keeps the three separate launches (A/B measurements).
+bool product_mid_applies(const nttx_plan* plan, size_t batch)
+{
+    static const bool off = std::getenv("NTTX_NO_PRODUCT_FUSION") != nullptr || std::getenv("NTTX_NO_CROSS_BATCH") != nullptr;
+    const size_t np = plan->passes.size();
+    if (off || np < 2 || batch < 16)
+        return false;
+    const PassDesc& d = plan->passes[np - 1];
+    return d.contig && d.k1 == 4 && d.k2 == 4 && !d.fused;
+}
+
+// product_mid_kernel on `count` (a multiple of 16) pairs at a, b.
+int launch_product_mid(const nttx_plan* plan, int slot, uint64_t* a, const uint64_t* b, size_t count, hipStream_t stream)
+{
+    const size_t np = plan->passes.size();
+    const PassDesc& d = plan->passes[np - 1];
+    const uint64_t tiles = ((uint64_t)count << plan->logn) / TILE;
+    if (tiles == 0 || tiles > 0x7fffffffull)
+        return fail(NTTX_EINVAL, "element count is out of range for one launch");
+    PassParams pf{};
+    pf.data = a;
+    pf.data2 = b;
+    pf.tw = plan->d_fwd[slot];
+    pf.tw_perm = plan->d_fwd_perm[slot];
+    pf.nblocks_total = (uint64_t)count << d.s0;
+    pf.block_base = 0;
+    pf.logB = plan->logn - d.s0;
+    pf.s0 = d.s0;
+    // The transforms only need to reach the range the product accepts: for q < 2^61 operands below 2q
+    // give hi(a * b) < q, so REDC still returns the canonical residue and the last conditional
+    // subtraction of both transforms is skipped (policies without a lazy range ignore the flag).
+    pf.flags = PASS_FINISH | PASS_LAZY | PASS_CROSS_BATCH;
+    if (!switches().no_buffer && plan->logn + 4 <= 28)
+        pf.flags |= PASS_OFFSET32;
+    apply_debug_flags(pf);
+    PassParams pb = pf;
+    pb.data2 = nullptr;
+    pb.tw = plan->d_inv[slot];
+    pb.tw_perm = plan->d_inv_perm[slot];
+    pb.flags &= ~(uint32_t)(PASS_FINISH | PASS_LAZY); // the product is canonical: no input conditioning either
+    hipError_t e;
+    switch (plan->policy) {
+    case nttx_plan::GOLDILOCKS: e = launch_product_mid_policy<Goldilocks>(pf, pb, plan->gctx, (unsigned)tiles, stream); break;
+    case nttx_plan::GOLDILOCKS_CANONICAL:
+        e = launch_product_mid_policy<GoldilocksCanonical>(pf, pb, plan->gctx, (unsigned)tiles, stream);
+        break;
+    case nttx_plan::MONT_WIDE: e = launch_product_mid_policy<Mont<true>>(pf, pb, plan->mctx_mul, (unsigned)tiles, stream); break;
+    case nttx_plan::MONT: e = launch_product_mid_policy<Mont<false>>(pf, pb, plan->mctx_mul, (unsigned)tiles, stream); break;
+    case nttx_plan::SHOUP61_NEAR: e = launch_product_mid_policy<Shoup61Near>(pf, pb, plan->sctx_mul, (unsigned)tiles, stream); break;
+    default: e = launch_product_mid_policy<Shoup61>(pf, pb, plan->sctx_mul, (unsigned)tiles, stream); break;
+    }
+    if (e != hipSuccess)
+        return fail(NTTX_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return NTTX_OK;
+}
+
 // a <- a * b in Z_q[X]/(X^n + 1) for `batch` pairs: forward(a), forward(b), then the backward
 // transform of a whose first pass multiplies by b element by element.  b == a squares (each tile
-// of the first backward pass is read completely before it is written).
+// of the first backward pass is read completely before it is written).  b is scratch: it ends
+// up holding its forward transform, or -- where product_mid_kernel ran -- the output of the
+// forward passes before the last.
 int enqueue_product(const nttx_plan* plan, int slot, uint64_t* a, uint64_t* b, size_t batch, hipStream_t stream)
 {
-    int rc = enqueue(plan, slot, a, batch, true, stream);
-    if (rc == NTTX_OK && b != a)
-        rc = enqueue(plan, slot, b, batch, true, stream);
+    if (batch == 0)
+        return NTTX_OK;
+    const uint64_t total = (uint64_t)batch << plan->logn;
+    if ((total >> plan->logn) != batch || total > (1ull << 40))
+        return fail(NTTX_EINVAL, "batch * n is too large");
+    if (!product_mid_applies(plan, batch)) {
+        int rc = enqueue(plan, slot, a, batch, true, stream);
+        if (rc == NTTX_OK && b != a)
+            rc = enqueue(plan, slot, b, batch, true, stream);
+        if (rc == NTTX_OK)
+            rc = enqueue(plan, slot, a, batch, false, stream, -1, b);
+        return rc;
+    }
+    const int np = (int)plan->passes.size();
+    const size_t mid = batch & ~(size_t)15, rest = batch - mid; // cross-batch tiles hold 16 transforms
+    uint64_t* const a_rest = a + ((uint64_t)mid << plan->logn);
+    uint64_t* const b_rest = b + ((uint64_t)mid << plan->logn);
+    int rc = NTTX_OK;
+    for (int i = 0; i + 1 < np && rc == NTTX_OK; i++) {
+        rc = enqueue_passes(plan, slot, a, batch, true, stream, i, nullptr, false);
+        if (rc == NTTX_OK && b != a)
+            rc = enqueue_passes(plan, slot, b, batch, true, stream, i, nullptr, false);
+    }
     if (rc == NTTX_OK)
-        rc = enqueue(plan, slot, a, batch, false, stream, -1, b);
+        rc = launch_product_mid(plan, slot, a, b, mid, stream);
+    if (rc == NTTX_OK && rest) { // fewer than 16 pairs left over: the separate launches
+        rc = enqueue_passes(plan, slot, a_rest, rest, true, stream, np - 1, nullptr, false);
+        if (rc == NTTX_OK && b != a)
+            rc = enqueue_passes(plan, slot, b_rest, rest, true, stream, np - 1, nullptr, false);
+        if (rc == NTTX_OK)
+            rc = enqueue_passes(plan, slot, a_rest, rest, false, stream, 0, b_rest, false);
+    }
+    // `b` here only selects the product's contexts (n^-1 * 2^64): pass 0 alone multiplies by it
+    for (int i = 1; i < np && rc == NTTX_OK; i++)
+        rc = enqueue_passes(plan, slot, a, batch, false, stream, i, b, false);
     return rc;
 }
 

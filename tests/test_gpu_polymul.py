@@ -8,6 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import _oracle as orc
+from _primes import MID
 
 Q61 = 0x1FFFFFFFFFE00001
 PSI61_2_21 = 0x0B4F9CB5C38B40B1
@@ -32,7 +33,11 @@ def make(amd, kind, n):
     psi = pow(7, (QGL - 1) // (2 * n), QGL)
     if kind == "montwide":   # the Goldilocks prime through the Montgomery table (ntt.rs:60-62)
         return amd.Table.from_prime_and_root(QGL, psi, n), orc.Table.from_prime_and_root(QGL, psi, n), QGL
-    return amd.TableGoldilock.from_root(psi, n), orc.TableGoldilock.from_root(psi, n), QGL
+    if kind == "goldilocks":
+        return amd.TableGoldilock.from_root(psi, n), orc.TableGoldilock.from_root(psi, n), QGL
+    q, root, _ = MID[1]   # strict Montgomery kernels (2^61 <= q < 2^63)
+    psi = pow(root, (1 << 20) // n, q)
+    return amd.Table.from_prime_and_root(q, psi, n), orc.Table.from_prime_and_root(q, psi, n), q
 
 
 def composition(ref, q, a, b, n):
@@ -97,10 +102,28 @@ def test_matches_composition_host_and_device(amd, kind, logn, batch):
     gpu.negacyclic_mul_inplace(da, db)
     torch.cuda.synchronize()
     assert np.array_equal(da.cpu().numpy().view(np.uint64), want), "device path"
-    fb = b.copy()
-    for i in range(batch):
-        ref.forward_inplace(fb[i * n:(i + 1) * n])
-    assert np.array_equal(db.cpu().numpy().view(np.uint64), fb), "b holds its forward transform afterwards"
+
+
+@pytest.mark.parametrize("kind", ["mont61", "mont32", "montwide", "goldilocks", "montstrict"])
+@pytest.mark.parametrize("batch", [16, 35])
+def test_fused_middle(amd, kind, batch):
+    """n = 2^16 with 16 or more pairs: the last forward pass of both operands, the product and the
+    first backward pass run in one launch on groups of 16 pairs; the pairs left over take the
+    separate launches.  Product and square, on device memory."""
+    import torch
+    n = 1 << 16
+    gpu, ref, q = make(amd, kind, n)
+    a = orc.splitmix_residues(q, n * batch, 400 + batch)
+    b = orc.splitmix_residues(q, n * batch, 500 + batch)
+    da = torch.from_numpy(a.view(np.int64).copy()).cuda()
+    db = torch.from_numpy(b.view(np.int64).copy()).cuda()
+    gpu.negacyclic_mul_inplace(da, db)
+    torch.cuda.synchronize()
+    assert np.array_equal(da.cpu().numpy().view(np.uint64), composition(ref, q, a, b, n))
+    ds = torch.from_numpy(a.view(np.int64).copy()).cuda()
+    gpu.negacyclic_mul_inplace(ds, ds)
+    torch.cuda.synchronize()
+    assert np.array_equal(ds.cpu().numpy().view(np.uint64), composition(ref, q, a, a, n))
 
 
 def test_square_and_overlap(amd):

@@ -26,5 +26,6 @@ for name, t, q in (("mont61", ntt_amd.Table.new(), 0x1FFFFFFFFFE00001),
 
     t3 = timed(three)
     tm = timed(lambda: t.negacyclic_mul_inplace(a, b))
-    print("%-10s batch %d x 2^16: product %.3f ms (%.0f products/s); forward, forward, backward alone %.3f ms"
-          % (name, batch, tm * 1e3, batch / tm, t3 * 1e3))
+    ts = timed(lambda: t.negacyclic_mul_inplace(a, a))
+    print("%-10s batch %d x 2^16: product %.3f ms (%.0f products/s), square %.3f ms; forward, forward, backward alone %.3f ms"
+          % (name, batch, tm * 1e3, batch / tm, ts * 1e3, t3 * 1e3))
