@@ -51,8 +51,10 @@ enum nttx_kind {
  *                    leaves them;
  *   NTTX_GOLDILOCKS: q must be 0xffffffff00000001, k is ignored, n_inv and both tables
  *                    are plain residues (ntt_goldilock.rs:12-14, 192-214).
- * n must be a power of two with even log2 (utils.rs:14-17 makes every odd log2 n panic in
- * the reference), 4 <= n <= 2^32.  For NTTX_MONT64 q must be odd (utils.rs:144-146) and k*q
+ * n must be a power of two, 4 <= n <= 2^32.  The reference only builds tables for even log2 n
+ * (utils.rs:14-17 makes every odd log2 n panic); tables for odd log2 n are taken to be in true
+ * bit-reversed order (entry bit_reverse(i) = psi^i), the order the index structure of
+ * ntt.rs:129-171 needs.  For NTTX_MONT64 q must be odd (utils.rs:144-146) and k*q
  * must be 1 mod 2^64 (utils.rs:148-152 yields a wrong k, hence wrong transforms, otherwise).
  * Tables (n entries each) are copied to every listed device; devices == NULL / n_devices == 0
  * means device 0 only.
@@ -66,7 +68,8 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
  * a C++ restatement of MontgomeryTransformer::from_modulus (utils.rs:141-162),
  * Table::from_prime_and_root + with_precomputes (ntt.rs:90-120, 239-261) and
  * TableGoldilock::with_precomputes (ntt_goldilock.rs:192-214).  For callers with no
- * host-side table code (tests, the benchmark, C and Python users).
+ * host-side table code (tests, the benchmark, C and Python users).  Like those constructors it
+ * refuses odd log2 n (they panic: utils.rs:14-17, ntt.rs:253).
  */
 int nttx_plan_create_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n,
                                const int *devices, int n_devices, nttx_plan **out);
@@ -77,7 +80,10 @@ int nttx_plan_create_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n,
  * negative Bezout coefficient by the modulus instead of 2^64 and so derives a k with k*q != 1 for
  * about half of all moduli (12289, 65537, 786433 ...), for which the reference's transforms are
  * wrong and nttx_plan_create / nttx_plan_create_from_root return NTTX_EINVAL.  With this entry
- * point those moduli work; where the reference's k is right the plan is identical.
+ * point those moduli work; where the reference's k is right the plan is identical.  It also lifts
+ * the reference's other setup defect: odd log2 n is accepted, with tables in true bit-reversed
+ * order (utils.rs:14-17 returns twice the reversal for an odd bit count).  Such plans run the
+ * batched entry points and the product; they are not split over shards.
  */
 int nttx_plan_create_from_root_exact_k(int kind, uint64_t q, uint64_t psi, uint64_t n,
                                        const int *devices, int n_devices, nttx_plan **out);

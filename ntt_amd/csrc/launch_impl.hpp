@@ -25,6 +25,15 @@ hipError_t launch_shape(const PassDesc& d, const PassParams& p, const typename A
     const int key = ((p.flags & PASS_CROSS_BATCH) ? 1000 : 0) + (d.contig ? 100 : 0) + d.k1 * 10 + d.k2;
     switch (key) {
     case 1144: return launch_one<A, FWD, true, 4, 4, true>(p, c, grid, s);
+    // odd stage counts: plans of the corrected constructor with odd log2 n
+    case 110: return launch_one<A, FWD, true, 1, 0>(p, c, grid, s);
+    case 130: return launch_one<A, FWD, true, 3, 0>(p, c, grid, s);
+    case 141: return launch_one<A, FWD, true, 4, 1>(p, c, grid, s);
+    case 143: return launch_one<A, FWD, true, 4, 3>(p, c, grid, s);
+    case 10: return launch_one<A, FWD, false, 1, 0>(p, c, grid, s);
+    case 30: return launch_one<A, FWD, false, 3, 0>(p, c, grid, s);
+    case 41: return launch_one<A, FWD, false, 4, 1>(p, c, grid, s);
+    case 43: return launch_one<A, FWD, false, 4, 3>(p, c, grid, s);
     case 120: return launch_one<A, FWD, true, 2, 0>(p, c, grid, s);
     case 140: return launch_one<A, FWD, true, 4, 0>(p, c, grid, s);
     case 142: return launch_one<A, FWD, true, 4, 2>(p, c, grid, s);

@@ -247,17 +247,43 @@ std::vector<PassDesc> make_passes(uint32_t logn)
 // Launches of a batched transform.  When log2 n = 2 or 4 mod 8 the short first pass of
 // make_passes is dropped: 8-stage STRIDED passes from stage 1 on, and the last 8 + (log2 n mod 8)
 // stages in one fused launch -- one HBM round trip fewer (NTTX_NO_FUSED_SMALL keeps make_passes).
+//
+// Odd log2 n > 8 (plans of the corrected constructor only): a first STRIDED pass with the largest odd
+// stage count r <= 7 that leaves a remainder the even schedule handles (a multiple of 8, or 2 or 4
+// more), then that schedule on the remaining stages: 2^17 = 7 + (8 + 2 fused), 2^21 = 5 + 8 + 8.
 std::vector<PassDesc> make_schedule(uint32_t logn)
 {
-    const uint32_t kf = logn % 8;
-    if ((kf != 2 && kf != 4) || logn < 10 || std::getenv("NTTX_NO_FUSED_SMALL") != nullptr)
+    static const bool no_fused = std::getenv("NTTX_NO_FUSED_SMALL") != nullptr;
+    uint32_t first = 0; // stages of the leading odd pass
+    if (logn > 8 && logn % 2 != 0) {
+        first = 1;
+        for (uint32_t r = 7; r > 1; r -= 2) {
+            const uint32_t m = logn >= r + 8 ? (logn - r) % 8 : 1;
+            if (m == 0 || m == 2 || m == 4) {
+                first = r;
+                break;
+            }
+        }
+    }
+    const uint32_t rest = logn - first, kf = rest % 8;
+    const bool fused_tail = (kf == 2 || kf == 4) && rest >= 10 && !no_fused;
+    if (first == 0 && !fused_tail)
         return make_passes(logn);
     std::vector<PassDesc> out;
-    for (uint32_t s0 = 0; s0 + 8 + kf < logn; s0 += 8)
-        out.push_back(PassDesc{4, 4, false, s0});
-    PassDesc tail{4, 4, true, logn - 8};
-    tail.fused = (int)kf;
-    out.push_back(tail);
+    if (first)
+        out.push_back(PassDesc{(int)std::min(first, 4u), first > 4 ? (int)first - 4 : 0, false, 0});
+    if (fused_tail) {
+        for (uint32_t s0 = first; s0 + 8 + kf < logn; s0 += 8)
+            out.push_back(PassDesc{4, 4, false, s0});
+        PassDesc tail{4, 4, true, logn - 8};
+        tail.fused = (int)kf;
+        out.push_back(tail);
+    } else {
+        for (PassDesc d : make_passes(rest)) { // the schedule of a transform of 2^rest elements, `first` stages later
+            d.s0 += first;
+            out.push_back(d);
+        }
+    }
     return out;
 }
 
@@ -369,7 +395,7 @@ int launch_pass(const nttx_plan* plan, int slot, const PassDesc& d, PassParams p
 int launch_fused(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream,
                  const uint64_t* mul_with, bool lazy)
 {
-    const int kf = (int)(plan->logn % 8);
+    const int kf = plan->passes.back().fused;
     const bool whole = plan->logn == (uint32_t)(8 + kf); // no stage precedes (forward) / follows (backward) this launch
     const uint64_t tiles = (((uint64_t)batch << plan->logn) + TILE - 1) / TILE;
     if (tiles == 0 || tiles > 0x7fffffffull)
@@ -603,6 +629,8 @@ int shard_geometry(const nttx_plan* plan, int n_shards, ShardGeom& g)
         return fail(NTTX_EINVAL, "number of shards must be a power of two in [1, 64]");
     if (plan->split_passes.size() < 2)
         return fail(NTTX_EINVAL, "n is too small to split (needs n >= 2^10)");
+    if (plan->logn % 2 != 0)
+        return fail(NTTX_EINVAL, "transforms with odd log2(n) are not split over shards");
     g.k = ntt::host::ilog2((uint64_t)n_shards);
     g.f = (uint32_t)(plan->split_passes[0].k1 + plan->split_passes[0].k2);
     if (g.f < g.k)
@@ -1404,9 +1432,6 @@ int check_plan_arguments(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t 
         return fail(NTTX_EINVAL, "unknown kind");
     if (n < 4 || n > (1ull << 32) || (n & (n - 1)) != 0)
         return fail(NTTX_EINVAL, "n must be a power of two in [4, 2^32]");
-    if (ntt::host::ilog2(n) % 2 != 0)
-        return fail(NTTX_EINVAL, "log2(n) must be even: the reference's bit_reverse (utils.rs:14-17) "
-                                 "indexes out of bounds for odd log2(n)");
     if (kind == NTTX_MONT64) {
         if ((q & 1) == 0 || q < 3)
             return fail(NTTX_EINVAL, "modulus is not coprime to helper modulus R=2^64");
@@ -1486,6 +1511,12 @@ static int plan_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n, const 
     *out = nullptr;
     if (n < 4 || n > (1ull << 32) || (n & (n - 1)) != 0)
         return fail(NTTX_EINVAL, "n must be a power of two in [4, 2^32]");
+    // The reference's constructors panic for odd log2(n) (bit_reverse, utils.rs:14-17, is no reversal
+    // then and with_precomputes indexes out of bounds, ntt.rs:253); only the corrected constructor
+    // builds such plans, with the tables of the true bit reversal.
+    if (!exact_k && ntt::host::ilog2(n) % 2 != 0)
+        return fail(NTTX_EINVAL, "log2(n) must be even: the reference's bit_reverse (utils.rs:14-17) "
+                                 "indexes out of bounds for odd log2(n)");
     static const bool host_tables = std::getenv("NTTX_HOST_TABLES") != nullptr;
     try {
         if (n >= DEVICE_TABLES_MIN_N && !host_tables && (kind == NTTX_MONT64 || kind == NTTX_GOLDILOCKS)) {
@@ -1494,9 +1525,6 @@ static int plan_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n, const 
             // out[j] depends on g^(n / 2^(k+1)) for 2^k <= j only) and the factor of every further level.
             if (kind == NTTX_MONT64 ? (q < 3 || psi == 0 || psi >= q) : (q != nttx::Goldilocks::Q || psi == 0 || psi >= q))
                 return fail(NTTX_EINVAL, kind == NTTX_MONT64 ? "need 0 < psi < q" : "NTTX_GOLDILOCKS requires q = 0xffffffff00000001 and 0 < psi < q");
-            if (ntt::host::ilog2(n) % 2 != 0)
-                return fail(NTTX_EINVAL, "log2(n) must be even: the reference's bit_reverse (utils.rs:14-17) "
-                                         "indexes out of bounds for odd log2(n)");
             const uint64_t seed = DEVICE_TABLES_SEED;
             const uint32_t logn = ntt::host::ilog2(n), logseed = ntt::host::ilog2(seed);
             TableSource src;
@@ -1562,7 +1590,7 @@ static int plan_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n, const 
                 return fail(NTTX_EINVAL, "NTTX_GOLDILOCKS requires q = 0xffffffff00000001");
             if (psi == 0 || psi >= q)
                 return fail(NTTX_EINVAL, "need 0 < psi < q");
-            auto t = ntt::host::build_goldilocks_tables(psi, n);
+            auto t = ntt::host::build_goldilocks_tables(psi, n, exact_k);
             return nttx_plan_create(kind, q, 0, n, t.n_inv, t.powers_psi_bo.data(), t.powers_psi_inv_bo.data(),
                                     devices, n_devices, out);
         }
@@ -1664,7 +1692,7 @@ int nttx_plan_tables(const nttx_plan* plan, uint64_t* psi_bo_out, uint64_t* psi_
                     f = std::move(t.powers_psi_bo);
                     b = std::move(t.powers_psi_inv_bo);
                 } else {
-                    auto t = ntt::host::build_goldilocks_tables(plan->psi, plan->n);
+                    auto t = ntt::host::build_goldilocks_tables(plan->psi, plan->n, plan->exact_k);
                     f = std::move(t.powers_psi_bo);
                     b = std::move(t.powers_psi_inv_bo);
                 }

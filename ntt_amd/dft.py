@@ -45,8 +45,10 @@ class _PlanTable(DFT):
     def __init__(self, q, psi, n, devices=None, exact_k=False):
         self.q, self.psi, self._n = q, psi, n
         self._plan = C.c_void_p()
-        # exact_k: q^-1 mod 2^64 for every odd modulus (the reference derives a wrong k for about half
-        # of them, utils.rs:148-152, and those are rejected otherwise); not the reference's behaviour
+        # exact_k: the corrected setup, not the reference's behaviour -- k = q^-1 mod 2^64 for every odd
+        # modulus (the reference derives a wrong k for about half of them, utils.rs:148-152, and those
+        # are rejected otherwise), and odd log2(n) with the true bit reversal (the reference's
+        # constructors panic there: utils.rs:14-17, ntt.rs:253)
         create = lib.nttx_plan_create_from_root_exact_k if exact_k else lib.nttx_plan_create_from_root
         if devices:
             arr = (C.c_int * len(devices))(*devices)
@@ -252,17 +254,19 @@ class TableGoldilock(_PlanTable):
     _kind = _lib.NTTX_GOLDILOCKS
     Q = 0xFFFFFFFF00000001
 
-    def __init__(self, psi, n, devices=None):
-        super().__init__(self.Q, psi, n, devices)
+    def __init__(self, psi, n, devices=None, corrected=False):
+        super().__init__(self.Q, psi, n, devices, corrected)
 
     @classmethod
     def new(cls, devices=None):  # ntt_goldilock.rs:48-58
         return cls(0xABD0A6E8AA3D8A0E, 1 << 16, devices)
 
     @classmethod
-    def from_root(cls, psi, n, devices=None):
-        """Same table for another (psi, n); the reference fixes both (ntt_goldilock.rs:50-52)."""
-        return cls(psi, n, devices)
+    def from_root(cls, psi, n, devices=None, corrected=False):
+        """Same table for another (psi, n); the reference fixes both (ntt_goldilock.rs:50-52).
+        corrected: accept odd log2(n) (true bit reversal; with_precomputes, ntt_goldilock.rs:192-214,
+        panics there)."""
+        return cls(psi, n, devices, corrected)
 
     @property
     def n_inv(self):

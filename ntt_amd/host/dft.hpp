@@ -277,10 +277,12 @@ class TableGoldilock<uint64_t> : public DFT<uint64_t> {
 
     static TableGoldilock new_() { return from_root(0xabd0a6e8aa3d8a0eull, 1ull << 16); } // ntt_goldilock.rs:48-58
 
-    // The same table for another (psi, n); the reference hard-codes both.
-    static TableGoldilock from_root(uint64_t psi, uint64_t n, const std::vector<int>& devices = {})
+    // The same table for another (psi, n); the reference hard-codes both.  corrected: odd log2(n) with
+    // the true bit reversal (with_precomputes, ntt_goldilock.rs:192-214, panics there).
+    static TableGoldilock from_root(uint64_t psi, uint64_t n, const std::vector<int>& devices = {},
+                                    bool corrected = false)
     {
-        host::GoldilocksTables t = host::build_goldilocks_tables(psi, n);
+        host::GoldilocksTables t = host::build_goldilocks_tables(psi, n, corrected);
         TableGoldilock out;
         out.q = host::GOLDILOCKS_Q;
         out.psi = psi;

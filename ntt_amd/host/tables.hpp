@@ -33,11 +33,14 @@ inline uint32_t ilog2(uint64_t n)
 // table is built by doubling instead -- out[2^k + j] = out[j] * g^(n / 2^(k+1)) for j < 2^k, because
 // bit_reverse(2^k + j) = bit_reverse(j) + n / 2^(k+1) -- which walks memory sequentially (the chain
 // scatters its 2^28 writes of the largest table over 2 GiB).
-// Odd log_n: the reference's bit_reverse (utils.rs:14-17) is not a reversal and indexes out of bounds.
+// Odd log_n: the reference's bit_reverse (utils.rs:14-17) is not a reversal and indexes out of bounds,
+// so its constructors panic; `any_log2` (the corrected constructors) builds the table of the true
+// bit reversal instead, which is what the doubling rule yields for every log_n.
 template <class Mul>
-inline void fill_bit_reversed_powers(std::vector<uint64_t>& out, uint32_t log_n, uint64_t one, uint64_t g, Mul mul)
+inline void fill_bit_reversed_powers(std::vector<uint64_t>& out, uint32_t log_n, uint64_t one, uint64_t g, Mul mul,
+                                     bool any_log2 = false)
 {
-    if (log_n % 2 != 0)
+    if (log_n % 2 != 0 && !any_log2)
         throw Panic("index out of bounds: bit_reverse is only a reversal for even log2(n)");
     std::vector<uint64_t> step(log_n ? log_n : 1); // step[k] = g^(n / 2^(k+1))
     uint64_t sq = g;
@@ -53,7 +56,8 @@ inline void fill_bit_reversed_powers(std::vector<uint64_t>& out, uint32_t log_n,
     }
 }
 
-// exact_k: use MontgomeryTransformer::from_modulus_exact (not the reference's behaviour).
+// exact_k: the corrected setup (not the reference's behaviour): MontgomeryTransformer::from_modulus_exact,
+// and odd log2(n) with the true bit reversal.
 inline MontgomeryTables build_montgomery_tables(uint64_t modulus, uint64_t root, uint64_t n, bool exact_k = false)
 {
     using utils::i128;
@@ -78,9 +82,9 @@ inline MontgomeryTables build_montgomery_tables(uint64_t modulus, uint64_t root,
     t.powers_psi_inv_bo.assign(n, 0);
     const auto& M = t.montgomery;
     fill_bit_reversed_powers(t.powers_psi_bo, log_n, tmp_psi, psi_montgomery,
-                             [&](uint64_t a, uint64_t b) { return M.mul(a, b); });
+                             [&](uint64_t a, uint64_t b) { return M.mul(a, b); }, exact_k);
     fill_bit_reversed_powers(t.powers_psi_inv_bo, log_n, tmp_psi_inv, t.psi_inv_montgomery,
-                             [&](uint64_t a, uint64_t b) { return M.mul(a, b); });
+                             [&](uint64_t a, uint64_t b) { return M.mul(a, b); }, exact_k);
     return t;
 }
 
@@ -117,7 +121,7 @@ struct GoldilocksTables {
 // TableGoldilock::new generalised over (psi, n): the reference fixes psi = 0xabd0a6e8aa3d8a0e,
 // n = 2^16, n_inv = 0xfffeffff00010001 (ntt_goldilock.rs:50-53); n_inv = q - (q-1)/n reproduces
 // that constant.  Tables as with_precomputes (ntt_goldilock.rs:192-214).
-inline GoldilocksTables build_goldilocks_tables(uint64_t psi, uint64_t n)
+inline GoldilocksTables build_goldilocks_tables(uint64_t psi, uint64_t n, bool any_log2 = false)
 {
     if (n == 0 || (n & (n - 1)) != 0 || (GOLDILOCKS_Q - 1) % n != 0)
         throw Panic("n must be a power of two dividing q - 1");
@@ -126,8 +130,8 @@ inline GoldilocksTables build_goldilocks_tables(uint64_t psi, uint64_t n)
     const uint32_t log_n = ilog2(n);
     t.powers_psi_bo.assign(n, 0);
     t.powers_psi_inv_bo.assign(n, 0);
-    fill_bit_reversed_powers(t.powers_psi_bo, log_n, 1, psi, goldilocks_mul_reduce);
-    fill_bit_reversed_powers(t.powers_psi_inv_bo, log_n, 1, psi_inv, goldilocks_mul_reduce);
+    fill_bit_reversed_powers(t.powers_psi_bo, log_n, 1, psi, goldilocks_mul_reduce, any_log2);
+    fill_bit_reversed_powers(t.powers_psi_inv_bo, log_n, 1, psi_inv, goldilocks_mul_reduce, any_log2);
     return t;
 }
 

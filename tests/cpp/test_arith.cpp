@@ -142,6 +142,21 @@ static void backward(std::vector<uint64_t>& a, const std::vector<typename A::TwE
     }
 }
 
+// Shoup61::pointwise is REDC: for operands below 2q (the lazy end of a forward transform) the result
+// is still the canonical a * b * 2^-64 mod q.
+static void pointwise_lazy_operands(uint64_t q)
+{
+    Shoup61Ctx sc = make_shoup61_ctx(q, 1, 1, ntt::utils::MontgomeryTransformer<uint64_t>::from_modulus_exact(q).k);
+    const uint64_t r_inv = ntt::utils::mod_exp_u64((uint64_t)((((u128)1) << 64) % q), q - 2, q); // 2^-64 mod q (q prime here)
+    std::mt19937_64 rng(q);
+    const uint64_t edge[] = {0, 1, q - 1, q, q + 1, 2 * q - 1};
+    for (int it = 0; it < 200000; it++) {
+        const uint64_t a = it % 3 ? rng() % (2 * q) : edge[rng() % 6], b = it % 5 ? rng() % (2 * q) : edge[rng() % 6];
+        const uint64_t got = Shoup61::pointwise(a, b, sc);
+        CHECK(got == mulmod(mulmod(a % q, b % q, q), r_inv, q));
+    }
+}
+
 // plain-arithmetic reference of the same transform (canonical residues)
 static void ref_forward(std::vector<uint64_t>& a, const std::vector<uint64_t>& w, uint64_t q)
 {
@@ -160,14 +175,28 @@ static void ref_forward(std::vector<uint64_t>& a, const std::vector<uint64_t>& w
     }
 }
 
-static void transform_tests(uint64_t q, uint64_t psi, size_t n)
+// corrected: the constructor that also takes odd log2 n (tables at the true bit reversal)
+static void transform_tests(uint64_t q, uint64_t psi, size_t n, bool corrected = false)
 {
-    auto mt = ntt::host::build_montgomery_tables(q, psi, n);
+    auto mt = ntt::host::build_montgomery_tables(q, psi, n, corrected);
     const auto& M = mt.montgomery;
     std::vector<uint64_t> plain_f(n), plain_b(n);
     for (size_t i = 0; i < n; i++) {
         plain_f[i] = M.reduce((u128)mt.powers_psi_bo[i]);
         plain_b[i] = M.reduce((u128)mt.powers_psi_inv_bo[i]);
+    }
+    {
+        // entry bit_reverse(i) of the forward table is psi^i, entry for entry its inverse in the other
+        const uint32_t bits = ntt::host::ilog2(n);
+        uint64_t pw = 1;
+        for (size_t i = 0; i < n; i++) {
+            size_t r = 0;
+            for (uint32_t b = 0; b < bits; b++)
+                r |= ((i >> b) & 1) << (bits - 1 - b);
+            CHECK(plain_f[r] == pw);
+            CHECK(mulmod(plain_f[r], plain_b[r], q) == 1);
+            pw = mulmod(pw, psi, q);
+        }
     }
     std::mt19937_64 rng(n ^ q);
     std::vector<uint64_t> in(n);
@@ -281,6 +310,20 @@ int main()
         transform_tests(Goldilocks::Q, ntt::utils::mod_exp_u64(0xabd0a6e8aa3d8a0eull, (1 << 16) / n, Goldilocks::Q), n);
         transform_tests(4293918721ull, ntt::utils::mod_exp_u64(2004365341ull, (1 << 16) / n, 4293918721ull), n);
     }
+    // odd log2 n: the reference's constructors panic, the corrected one builds the true table
+    for (size_t n : {8, 32, 512, 2048}) {
+        bool threw = false;
+        try {
+            (void)ntt::host::build_montgomery_tables(q61, ntt::utils::mod_exp_u64(psi61, (1 << 16) / n, q61), n);
+        } catch (const ntt::Panic&) {
+            threw = true;
+        }
+        CHECK(threw);
+        transform_tests(q61, ntt::utils::mod_exp_u64(psi61, (1 << 16) / n, q61), n, true);
+        transform_tests(Goldilocks::Q, ntt::utils::mod_exp_u64(0xabd0a6e8aa3d8a0eull, (1 << 16) / n, Goldilocks::Q), n, true);
+    }
+    pointwise_lazy_operands(q61);
+    pointwise_lazy_operands(4293918721ull);
     goldilocks_tests();
     if (failures == 0)
         std::printf("all arithmetic tests passed\n");

@@ -28,8 +28,10 @@ def test_argument_validation_needs_no_gpu():
     plan = C.c_void_p()
     tab = (C.c_uint64 * 16)(*([1] * 16))
     q61, k61 = 0x1FFFFFFFFFE00001, 6917533425689690113
-    # odd log2 n (utils.rs:14-17 makes the reference panic)
-    assert lib.nttx_plan_create(0, q61, k61, 8, 1, tab, tab, None, 0, C.byref(plan)) == _lib.NTTX_EINVAL
+    # odd log2 n (utils.rs:14-17 makes the reference's constructors panic)
+    assert lib.nttx_plan_create_from_root(0, q61, 3, 8, None, 0, C.byref(plan)) == _lib.NTTX_EINVAL
+    assert "even" in _lib.last_error()
+    assert lib.nttx_plan_create_from_root(1, 0xFFFFFFFF00000001, 3, 32, None, 0, C.byref(plan)) == _lib.NTTX_EINVAL
     assert "even" in _lib.last_error()
     # even modulus (utils.rs:144-146)
     assert lib.nttx_plan_create(0, 1 << 20, 1, 16, 1, tab, tab, None, 0, C.byref(plan)) == _lib.NTTX_EINVAL
