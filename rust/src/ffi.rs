@@ -22,7 +22,8 @@ extern "C" {
         devices: *const c_int, n_devices: c_int, out: *mut *mut NttxPlan,
     ) -> c_int;
     /// Not reference behaviour: k = q^-1 mod 2^64 for every odd q (utils.rs:148-152 gets about
-    /// half of all moduli wrong, and the two constructors above reject those).
+    /// half of all moduli wrong, and the two constructors above reject those); also accepts odd
+    /// log2 n, with tables at the true bit reversal (utils.rs:14-17 panics there).
     pub fn nttx_plan_create_from_root_exact_k(
         kind: c_int, q: u64, psi: u64, n: u64,
         devices: *const c_int, n_devices: c_int, out: *mut *mut NttxPlan,
