@@ -1966,6 +1966,6 @@ int nttx_device_count(void)
 }
 
 const char* nttx_last_error(void) { return g_err.c_str(); }
-const char* nttx_version(void) { return "nttx 0.1 (gfx950)"; }
+const char* nttx_version(void) { return "nttx 0.2 (gfx950)"; }
 
 } // extern "C"
