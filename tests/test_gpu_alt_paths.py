@@ -25,7 +25,7 @@ def test_parity_on_alternative_paths(switches):
     for s in switches:
         env[s] = "1"
     cmd = [sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_gpu_polymul.py"),
-           "-x", "-q", "-p", "no:cacheprovider", "-k", SELECT + " or composition"]
+           "-x", "-q", "-p", "no:cacheprovider", "-k", SELECT + " or composition or fused_middle"]
     out = subprocess.run(cmd, env=env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout and "failed" not in out.stdout
