@@ -5,7 +5,7 @@
  * own: the boundary it exposes is the `DFT<O>` trait (src/dft.rs:6-11) and the
  * three table types that implement it.  Each entry point below names the
  * reference interface whose body it replaces.  A Rust `extern "C"` block that
- * binds exactly these symbols is shown in INTEGRATION.md.
+ * binds exactly these symbols is rust/src/ffi.rs.
  *
  * Conventions: plain pointers and sizes; no exceptions cross the boundary;
  * every function returns an nttx_status (0 = ok) and leaves a message readable
