@@ -6,7 +6,7 @@ libnttx.so (hand-written gfx950 kernels behind the C ABI of include/nttx.h); the
 CPU fallback: importing this package fails if the library has not been built.
 """
 from . import _lib  # noqa: F401  (loads libnttx.so or raises)
-from . import dft, distributed, utils  # noqa: F401
+from . import avx2, dft, distributed, utils  # noqa: F401
 from .dft import DFT, Panic, Table, TableAVX2, TableGoldilock  # noqa: F401
 
-__all__ = ["dft", "utils", "DFT", "Panic", "Table", "TableAVX2", "TableGoldilock"]
+__all__ = ["avx2", "dft", "utils", "DFT", "Panic", "Table", "TableAVX2", "TableGoldilock"]
