@@ -383,10 +383,19 @@ def test_baseline_sizes_device_resident(amd, workload):
     out = [data[b * n:(b + 1) * n].cpu().numpy().view(np.uint64) for b in (0, 1, 2)]
     lin = np.array([(int(a) + int(b)) % q for a, b in zip(out[0] % np.uint64(q), out[1] % np.uint64(q))], dtype=np.uint64)
     assert np.array_equal(out[2] % np.uint64(q), lin)
-    for b in (0, batch // 2 + 1, batch - 1):
+    # 64 (mont16) / 8 (goldilocks20) transforms spread over the batch, first and last included, against
+    # the oracle -- for the Montgomery kind against both of its restatements (scalar and AVX2)
+    count = 64 if workload == "mont16" else 8
+    avx = orc.TableAVX2.new() if workload == "mont16" else None
+    for b in sorted({(i * (batch - 1)) // (count - 1) for i in range(count)} | {batch // 2 + 1}):
+        got = data[b * n:(b + 1) * n].cpu().numpy().view(np.uint64)
         want = original[b * n:(b + 1) * n].cpu().numpy().view(np.uint64).copy()
         ref.forward_inplace(want)
-        assert np.array_equal(data[b * n:(b + 1) * n].cpu().numpy().view(np.uint64), want)
+        assert np.array_equal(got, want), b
+        if avx is not None:
+            w2 = original[b * n:(b + 1) * n].cpu().numpy().copy()
+            avx.forward_inplace(w2)
+            assert np.array_equal(got, w2.view(np.uint64)), b
     gpu.backward_inplace(data)
     torch.cuda.synchronize()
     assert torch.equal(data, original)
