@@ -58,17 +58,23 @@ def launch_ranks(argv, gpus):
     return subprocess.call(cmd)
 
 
-def rank_device(local_rank):
-    """Device of a local rank and whether ranks share devices (more ranks than visible GPUs: a
-    rehearsal on a smaller box; RCCL refuses two ranks on one device, so those runs line ranks up
-    over gloo).  torch.cuda.device_count() does not initialise the GPU."""
+def rank_device(local_rank, allow_shared):
+    """Device of a local rank, whether ranks share devices, and the number of distinct devices the job
+    runs on.  More ranks than visible GPUs is refused unless --allow-shared-devices is given (a
+    rehearsal of the multi-rank path on a smaller box: RCCL refuses two ranks on one device, so
+    those runs line ranks up over gloo, and the record reports the distinct devices as n_gpus).
+    torch.cuda.device_count() does not initialise the GPU."""
     import torch
 
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("no GPU visible")
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    return local_rank % ndev, world > ndev
+    if world > ndev and not allow_shared:
+        raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible; ranks would share devices and the "
+                         "record would not measure %d GPUs (--allow-shared-devices rehearses the path anyway)"
+                         % (world, ndev, world))
+    return local_rank % ndev, world > ndev, min(world, ndev)
 
 
 def cpu_model():
@@ -125,7 +131,7 @@ def run_split(args, json_fd):
     rank, world, local_rank = (int(os.environ[k]) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    local_rank, shared = rank_device(local_rank)
+    local_rank, shared, distinct = rank_device(local_rank, args.allow_shared_devices)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if shared:
@@ -203,13 +209,14 @@ def run_split(args, json_fd):
     if rank == 0:
         out = {
             "metric": "single N=2^%d fwd+inv NTTs/sec per node; %% of HBM roofline" % logn,
-            "value": round(value, 2), "unit": "fwd+inv NTT pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "value": round(value, 2), "unit": "fwd+inv NTT pairs/s", "n_gpus": distinct, "ranks": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload][3] % 1 if logn == 28 else "1 x N=2^%d Goldilocks, split" % logn,
                        "n": n, "modulus": hex(QGL), "shards": world, "rows_per_peer": st.rows_per_peer,
-                       "sharding": "column slabs, one all-to-all per direction, contiguous slabs"},
-            "hbm_roofline_frac": round(value * 32 * n / (world * HBM_PEAK_GBS * 1e9), 4),
+                       "sharding": "column slabs, one all-to-all per direction, contiguous slabs"
+                                   + (", ranks share devices (rehearsal)" if shared else "")},
+            "hbm_roofline_frac": round(value * 32 * n / (distinct * HBM_PEAK_GBS * 1e9), 4),
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes / dom["launches"],
@@ -232,6 +239,9 @@ def main():
     ap.add_argument("--total-batch", type=int, default=0,
                     help="transforms of the whole job, split contiguously over the ranks (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-shared-devices", action="store_true",
+                    help="let --gpus exceed the visible GPUs (ranks share devices, gloo barrier): a rehearsal, "
+                         "reported with n_gpus = distinct devices and \"ranks\" = --gpus")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the round-trip checks (timing runs with the NTTX_DEBUG_* profiling switches, whose "
                          "results are meaningless on purpose); the record is marked invalid")
@@ -241,6 +251,13 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
     if "RANK" not in os.environ and (args.gpus > 1 or args.workload == "goldilocks28split"):
+        import torch  # device_count() does not initialise the GPU
+
+        if args.gpus > torch.cuda.device_count() and not args.allow_shared_devices:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible; refusing to share devices between ranks "
+                             "(--allow-shared-devices rehearses the multi-rank path and reports the distinct "
+                             "devices as n_gpus)\n" % (args.gpus, torch.cuda.device_count()))
+            sys.exit(2)
         sys.exit(launch_ranks(sys.argv[1:], args.gpus))
 
     # stdout carries the JSON line and nothing else: libraries that write to file descriptor 1
@@ -267,7 +284,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    local_rank, shared = rank_device(local_rank)
+    local_rank, shared, distinct = rank_device(local_rank, args.allow_shared_devices)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -349,7 +366,7 @@ def main():
         raise SystemExit("round trip failure after the timed region")
 
     value = job_batch * args.steps / elapsed  # units all ranks processed / the slowest rank's time
-    frac_job = value * 32 * N / (world * HBM_PEAK_GBS * 1e9)
+    frac_job = value * 32 * N / (distinct * HBM_PEAK_GBS * 1e9)
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, per pass -----------
     stream = torch.cuda.current_stream(dev)
@@ -387,19 +404,56 @@ def main():
     # are the ones they were measured on and the batch is the one they were measured at
     at_default = batch == default_batch
     traffic = recorded_counter("traffic", args.workload, dom["name"]) if at_default else None
+    # Shader clock while the dominant kernel runs: a one-wave probe on a second stream reads the
+    # shader-cycle and the 100 MHz counters around a 2 ms spin while that kernel is launched back to
+    # back on the main stream (nttx_clock_probe_device).  The chip is power-limited under this load,
+    # so the clock -- not the 2.4 GHz of the data sheet -- turns an instruction count into time.
+    clock_mhz = None
+    di = kernels.index(dom)
+    probe_out = torch.zeros(2, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    if di % npass == 0:
+        data.copy_(original)
+    torch.cuda.synchronize()
+    for r in range(12):
+        lib.nttx_run_pass_device(table._plan, local_rank, data.data_ptr(), batch, di // npass, di % npass, stream.cuda_stream)
+        if r == 2:
+            lib.nttx_clock_probe_device(local_rank, probe_out.data_ptr(), 2000, side.cuda_stream)
+    torch.cuda.synchronize()
+    cyc, ticks = (int(v) for v in probe_out.cpu())
+    if ticks > 0 and cyc > 0:
+        clock_mhz = 100.0 * cyc / ticks
+    # leave `data` as the timed loop left it: these launches ran out of sequence
+    data.copy_(original)
+
     # second bound: integer VALU.  Wave-level VALU instructions per launch of that kernel
     # (SQ_INSTS_VALU); a wave64 instruction holds its SIMD for about 4 cycles (the multiplies and
-    # 64-bit forms that make up most of a butterfly: tools/ubench_issue.hip), 1024 SIMDs at 2.4 GHz.
+    # 64-bit forms that make up most of a butterfly: tools/ubench_issue.hip) on 1024 SIMDs, priced at
+    # the clock measured above.
     valu = None
     insts = recorded_counter("valu", args.workload, dom["name"]) if at_default else None
     if insts:
-        valu = {"wave_instructions_per_launch": insts,
-                "issue_utilisation": round(insts * 4 / (dom["avg_ms"] * 1e-3 * 1024 * 2.4e9), 3)}
+        ghz = (clock_mhz or 2400.0) / 1e3
+        valu = {"wave_instructions_per_launch": insts, "clock_mhz": round(clock_mhz, 1) if clock_mhz else None,
+                "cycles_per_instruction": 4,
+                "issue_utilisation": round(insts * 4 / (dom["avg_ms"] * 1e-3 * 1024 * ghz * 1e9), 3),
+                "issue_utilisation_at_2400_mhz": round(insts * 4 / (dom["avg_ms"] * 1e-3 * 1024 * 2.4e9), 3)}
+    elif clock_mhz:
+        valu = {"clock_mhz": round(clock_mhz, 1)}
+    # measured floors of the whole step (profiling build, tools/floors.sh): butterflies switched off
+    # (memory only) and every workgroup on 64 L2-resident tiles (compute only)
+    floors = None
+    if at_default:
+        mem_ms = recorded_counter("floors", args.workload, "memory_only_ms")
+        cmp_ms = recorded_counter("floors", args.workload, "compute_only_ms")
+        if mem_ms and cmp_ms:
+            floors = {"memory_only_ms": mem_ms, "compute_only_ms": cmp_ms,
+                      "shipped_ms_same_run": recorded_counter("floors", args.workload, "shipped_ms")}
     roofline = {
         "bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom["avg_ms"], 4),
-        "whole_job_frac": round(frac_job, 4), "valu": valu,
+        "whole_job_frac": round(frac_job, 4), "valu": valu, "floors": floors,
         "kernels": [{"name": k["name"], "avg_ms": round(k["avg_ms"], 4)} for k in kernels],
     }
 
@@ -442,14 +496,14 @@ def main():
         out = {
             "metric": "batched N=2^%d fwd+inv NTTs/sec per node; %% of HBM roofline" % LOGN,
             "value": round(value, 1), "unit": "fwd+inv NTT pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": distinct, "ranks": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": (describe % job_batch).replace("per GPU", "in the job, split over %d GPUs" % world)
                        if strong else describe % batch, "batch_per_gpu": batch,
                        "job_batch": job_batch, "n": N, "modulus": hex(q),
-                       "sharding": "batch split, no collective" + (", ranks share devices" if shared else "")},
+                       "sharding": "batch split, no collective" + (", ranks share devices (rehearsal)" if shared else "")},
             "hbm_roofline_frac": round(frac_job, 4),
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -191,6 +191,16 @@ int nttx_pass_count(const nttx_plan *plan);
 int nttx_pass_describe(const nttx_plan *plan, int dir, int pass_index, char *buf, size_t buf_len);
 int nttx_run_pass_device(const nttx_plan *plan, int device, void *dptr, size_t batch, int dir,
                          int pass_index, void *hip_stream);
+/*
+ * Shader clock under load (no counterpart in the reference; a measurement aid like the three above).
+ * Enqueues on hip_stream a one-wave kernel that reads the shader-clock counter and the constant
+ * 100 MHz counter, spins for about spin_us microseconds (at most 100 000) and reads both again;
+ * out2 (device memory, two uint64_t) receives {shader cycles, 100 MHz ticks} elapsed, so the clock
+ * in MHz is 100 * out2[0] / out2[1].  Enqueued on a second stream while transforms run on the
+ * first, it reports the clock the chip holds under that load, which is what prices a kernel's
+ * instruction count in time.
+ */
+int nttx_clock_probe_device(int device, uint64_t *out2, int spin_us, void *hip_stream);
 
 /*
  * ONE transform of n elements split over n_shards = 2^k shards (a single vector too large or

@@ -19,8 +19,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define NTTX_HD __host__ __device__ __forceinline__
+#define NTTX_UNROLL _Pragma("unroll")
 #else
 #define NTTX_HD inline
+#define NTTX_UNROLL
 #endif
 
 namespace nttx {
@@ -194,11 +196,13 @@ struct Shoup61Ctx {
     uint64_t q, q2, q4;
     uint64_t nq;   // 2^64 - q
     uint32_t c8;   // NEAR: 2^61 - q
-    uint32_t pad_;
+    uint32_t scale_shift; // k when `scale` is 2^-k mod q with q = 1 mod 2^k (n^-1 of a transform of 2^k points), else 0
     TwPair one;    // (1, floor(2^64 / q)): reduces an arbitrary u64 input
     TwPair scale;  // n^-1 (plain residue) and its quotient
     TwPair scale1; // tw[1] * n^-1 mod q and its quotient (twiddle of inverse stage 1, pre-scaled)
     uint64_t k;    // q^-1 mod 2^64 (utils.rs:130), for the product of two data words
+    uint64_t qk;   // scale_shift != 0: (q - 1) >> scale_shift
+    uint64_t qk1;  // scale_shift != 0: qk + 1
 };
 
 // True when the NEAR forms apply to q.
@@ -218,6 +222,18 @@ inline Shoup61Ctx make_shoup61_ctx(uint64_t q, uint64_t n_inv_plain, uint64_t s1
     c.scale = pair_of(n_inv_plain);
     c.scale1 = pair_of(s1_plain);
     c.k = k;
+    // n^-1 = 2^-j for a transform of 2^j points, and 2n | q - 1 for any modulus that has such a
+    // transform: then scaling is a division by 2^j made exact by a multiple of q (mul_pow2_inv).
+    // Limits of that routine: t < 2^24 and hi32(qk) < 2^24 for its 24-bit multiply.
+    for (uint32_t j = 8; j <= 24; j++) {
+        if ((uint64_t)(((unsigned __int128)n_inv_plain << j) % q) == 1 % q && ((q - 1) & ((1ull << j) - 1)) == 0 &&
+            ((q - 1) >> j >> 32) < (1u << 24)) {
+            c.scale_shift = j;
+            c.qk = (q - 1) >> j;
+            c.qk1 = c.qk + 1;
+            break;
+        }
+    }
     return c;
 }
 
@@ -343,12 +359,76 @@ struct Shoup61T {
         return csub(csub(x, c.q2), c.q);
     }
 
+    // x * 2^-k mod q for k = c.scale_shift (q = 1 mod 2^k), any x < 2^64, without a product by a
+    // quotient: with t = ~x mod 2^k the sum x + (t + 1) q is a multiple of 2^k, and
+    //   (x + (t + 1) q) / 2^k = (x >> k) + 1 + (t + 1) qk = (x >> k) + (qk + 1) + t * qk,  qk = (q - 1) >> k.
+    // Six instructions against eleven; the result lies in [0, q + 2^(64-k)): almost always canonical,
+    // always below 2q.
+    static NTTX_HD uint64_t mul_pow2_inv(uint64_t x, const Ctx& c)
+    {
+        const uint32_t t = ~lo32(x) & ((1u << c.scale_shift) - 1);
+        const uint64_t r = mad32u(t, lo32(c.qk), add64u(x >> c.scale_shift, c.qk1));
+#if defined(__HIP_DEVICE_COMPILE__)
+        return pack64(lo32(r), hi32(r) + __umul24(t, hi32(c.qk))); // one v_mad_u32_u24: both factors below 2^24
+#else
+        return pack64(lo32(r), hi32(r) + t * hi32(c.qk));
+#endif
+    }
+
     // Stage 1 of the inverse with the n^-1 factor of ntt.rs:231-235 folded in; canonical outputs.
     static NTTX_HD void gs_last(uint64_t& a, uint64_t& b, const Tw&, const Ctx& c)
     {
         const uint64_t u = a, v = b;
-        a = canon4(mul(add64(u, v), make(c.scale), c), c);
+        if (c.scale_shift)
+            a = csub(mul_pow2_inv(add64(u, v), c), c.q);
+        else
+            a = canon4(mul(add64(u, v), make(c.scale), c), c);
         b = canon4(mul(sub64(add64u(u, c.q4), v), make(c.scale1), c), c);
+    }
+
+    // The same stage on a whole register group (x[i] with x[i + M/2]).  NEAR: every output is first
+    // brought below 2q by a route that almost never leaves it at q or above (fold61 of a product:
+    // only for values within 7 c8 of a multiple of 2^61; mul_pow2_inv: with probability about
+    // 2^(3-k)); one comparison of the largest high word with q's decides whether the group needs the
+    // conditional subtractions at all.  7 -> 3.5 instructions per output, results identical.
+    template <int M>
+    static NTTX_HD void gs_last_stage(uint64_t (&x)[M], const Tw& s, const Ctx& c)
+    {
+        constexpr int half = M / 2;
+        if (!NEAR) {
+            NTTX_UNROLL
+            for (int i = 0; i < half; i++)
+                gs_last(x[i], x[i + half], s, c);
+            return;
+        }
+        uint32_t top = 0;
+        if (c.scale_shift) {
+            NTTX_UNROLL
+            for (int i = 0; i < half; i++) {
+                const uint64_t u = x[i], v = x[i + half];
+                x[i] = mul_pow2_inv(add64(u, v), c);
+                x[i + half] = fold61(mul(sub64(add64u(u, c.q4), v), make(c.scale1), c), c);
+                top = max3(top, hi32(x[i]), hi32(x[i + half]));
+            }
+        } else {
+            NTTX_UNROLL
+            for (int i = 0; i < half; i++) {
+                const uint64_t u = x[i], v = x[i + half];
+                x[i] = fold61(mul(add64(u, v), make(c.scale), c), c);
+                x[i + half] = fold61(mul(sub64(add64u(u, c.q4), v), make(c.scale1), c), c);
+                top = max3(top, hi32(x[i]), hi32(x[i + half]));
+            }
+        }
+        if (__builtin_expect(top >= hi32(c.q), 0)) {
+            NTTX_UNROLL
+            for (int i = 0; i < M; i++)
+                x[i] = csub(x[i], c.q);
+        }
+    }
+    static NTTX_HD uint32_t max3(uint32_t x, uint32_t y, uint32_t z)
+    {
+        const uint32_t m = x > y ? x : y;
+        return m > z ? m : z;
     }
 
     // Lazy outputs: the range [0, 2q) the reference documents for forward_inplace_lazy /
@@ -393,6 +473,31 @@ struct Shoup61T {
         if (NEAR)
             return csub(fold61(x, c), c.q);
         return canon4(csub(x, c.q4), c);
+    }
+    // The same for a register group.  NEAR: fold61 leaves a value at q or above only when the input
+    // lies within 7 c8 below a multiple of 2^61 (probability about 2^-37 c8 per element), so the
+    // conditional subtractions hide behind one comparison of the group's largest high word.
+    template <int M>
+    static NTTX_HD void finish_group(uint64_t (&x)[M], const Ctx& c)
+    {
+        if (!NEAR) {
+            NTTX_UNROLL
+            for (int i = 0; i < M; i++)
+                x[i] = finish(x[i], c);
+            return;
+        }
+        uint32_t top = 0;
+        NTTX_UNROLL
+        for (int i = 0; i < M; i += 2) {
+            x[i] = fold61(x[i], c);
+            x[i + 1] = fold61(x[i + 1], c);
+            top = max3(top, hi32(x[i]), hi32(x[i + 1]));
+        }
+        if (__builtin_expect(top >= hi32(c.q), 0)) {
+            NTTX_UNROLL
+            for (int i = 0; i < M; i++)
+                x[i] = csub(x[i], c.q);
+        }
     }
 };
 using Shoup61 = Shoup61T<false>;
@@ -484,6 +589,15 @@ struct Mont {
     static NTTX_HD uint64_t pointwise(uint64_t a, uint64_t b, const Ctx& c) { return mul(a, b, c); }
 
     static NTTX_HD uint64_t finish(uint64_t x, const Ctx&) { return x; }
+    template <int M>
+    static NTTX_HD void finish_group(uint64_t (&)[M], const Ctx&) {}
+    template <int M>
+    static NTTX_HD void gs_last_stage(uint64_t (&x)[M], const Tw& s, const Ctx& c)
+    {
+        NTTX_UNROLL
+        for (int i = 0; i < M / 2; i++)
+            gs_last(x[i], x[i + M / 2], s, c);
+    }
 
     // strict residues throughout: the canonical outputs already lie in the lazy range [0, 2q)
     static constexpr bool HAS_LAZY = false;
@@ -841,6 +955,8 @@ struct Goldilocks {
 
     static NTTX_HD uint64_t condition_input(uint64_t x, const Ctx&) { return x; }
     static NTTX_HD uint64_t finish(uint64_t x, const Ctx&) { return x; }
+    template <int M>
+    static NTTX_HD void finish_group(uint64_t (&)[M], const Ctx&) {}
     // TableGoldilock's lazy methods run the same statements as its strict ones (ntt_goldilock.rs:25-29, 39-43)
     static constexpr bool HAS_LAZY = false;
     static NTTX_HD uint64_t finish_lazy(uint64_t x, const Ctx&) { return x; }
@@ -858,6 +974,13 @@ struct GoldilocksCanonical : Goldilocks {
     static constexpr bool CONDITIONS_INPUT = true;
     static NTTX_HD uint64_t condition_input(uint64_t x, const Ctx&) { return x >= Q ? x - Q : x; }
     static NTTX_HD uint64_t finish(uint64_t x, const Ctx&) { return x == Q ? 0 : x; }
+    template <int M>
+    static NTTX_HD void finish_group(uint64_t (&x)[M], const Ctx& c)
+    {
+        NTTX_UNROLL
+        for (int i = 0; i < M; i++)
+            x[i] = finish(x[i], c);
+    }
 };
 
 } // namespace nttx

@@ -32,10 +32,20 @@ constexpr int THREADS = 256;             // 4 waves
 constexpr int REGS = TILE / THREADS;     // 16 elements per thread
 constexpr int LDS_ELEMS = TILE + TILE / 16;
 
+// The PASS_DEBUG_* switches skip work or redirect traffic and so produce wrong results on purpose.
+// They are compiled in only with -DNTTX_PROFILING (libnttx_prof.so, `make prof`); in the shipped
+// library NTTX_PROF() folds every test of them to false and the code behind them disappears.
+#ifdef NTTX_PROFILING
+#define NTTX_PROF(cond) (cond)
+#else
+#define NTTX_PROF(cond) false
+#endif
+
 enum : uint32_t {
     PASS_CONDITION_INPUT = 1u, // first pass of a transform: map arbitrary u64 input to residues
     PASS_SCALE = 2u,           // pass holding stage 1 of the inverse: fold the n^-1 factor in
     PASS_FINISH = 4u,          // last pass of the forward transform: store canonical residues
+    // the four PASS_DEBUG_* flags act in profiling builds only (NTTX_PROF above)
     PASS_DEBUG_NO_MATH = 8u,   // profiling aid (NTTX_DEBUG_NO_MATH=1): skip the butterflies, keep all traffic
     PASS_DEBUG_NO_TW = 16u,    // profiling aid (NTTX_DEBUG_NO_TW=1, with NO_MATH): skip the twiddle loads too
     PASS_DEBUG_NO_MATH_A = 32u, // profiling aids (NTTX_DEBUG_NO_MATH=A / B): skip one register round of the 8-stage pass
@@ -44,9 +54,6 @@ enum : uint32_t {
     PASS_POINTWISE = 256u,     // first pass of a backward transform: multiply by the vector at data2 first
     PASS_OFFSET32 = 512u,      // every element of a tile lies within 2^31 bytes of the tile's first: buffer addressing
     PASS_LAZY = 1024u,         // outputs of the transform in the policy's lazy range ([0, 2q)) instead of canonical
-    PASS_COHERENT_LOADS = 4096u, // data loads bypass the CU's vector L1 (sc1): the tile was written by other
-                               // workgroups of the same launch on the same XCD (fused16_kernel)
-    PASS_CACHED_STORES = 8192u,  // data stores with the default cache policy: the tile is re-read from L2 soon
     PASS_DEBUG_HOT_TILES = 2048u // profiling aid (NTTX_DEBUG_HOT_TILES=1): every workgroup works on one of the first 64
                                // tiles, so all traffic is served by the L2s -- the pass time with HBM out of the picture
 };
@@ -196,32 +203,36 @@ __device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const Src& w, const
             }
         }
     } else {
+        // stages K .. 2, then stage 1 on its own: it is the one that may carry the n^-1 factor, and its
+        // code inside the loop would count K times against the unroller's size limit
 #pragma unroll
-        for (int u = K; u >= 1; u--) {
+        for (int u = K; u >= 2; u--) {
             const int half = M >> u;
-            if (u == 1 && scale) {
-                // last stage of the inverse with the n^-1 factor folded in (ntt.rs:231-235)
-                const typename A::Tw s = w.get(1);
-                if (A::HAS_LAZY && scale == SCALE_LAZY) {
 #pragma unroll
-                    for (int i = 0; i < half; i++)
-                        A::gs_last_lazy(x[i], x[i + half], s, c);
-                } else {
+            for (int b = 0; b < (1 << (u - 1)); b++) {
+                const typename A::Tw s = w.get((1 << (u - 1)) + b);
 #pragma unroll
-                    for (int i = 0; i < half; i++)
-                        A::gs_last(x[i], x[i + half], s, c);
-                }
-            } else {
-#pragma unroll
-                for (int b = 0; b < (1 << (u - 1)); b++) {
-                    const typename A::Tw s = w.get((1 << (u - 1)) + b);
-#pragma unroll
-                    for (int i = 0; i < half; i++) {
-                        const int lo = b * 2 * half + i;
-                        A::gs(x[lo], x[lo + half], s, c);
-                    }
+                for (int i = 0; i < half; i++) {
+                    const int lo = b * 2 * half + i;
+                    A::gs(x[lo], x[lo + half], s, c);
                 }
             }
+        }
+        constexpr int half = M >> 1;
+        const typename A::Tw s = w.get(1);
+        if (scale) {
+            // last stage of the inverse with the n^-1 factor folded in (ntt.rs:231-235)
+            if (A::HAS_LAZY && scale == SCALE_LAZY) {
+#pragma unroll
+                for (int i = 0; i < half; i++)
+                    A::gs_last_lazy(x[i], x[i + half], s, c);
+            } else {
+                A::template gs_last_stage<M>(x, s, c);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < half; i++)
+                A::gs(x[i], x[i + half], s, c);
         }
     }
 }
@@ -368,7 +379,6 @@ __device__ __forceinline__ void buffer_store64(__amdgpu_buffer_rsrc_t r, uint32_
     const u32x2_t v = {lo32(x), hi32(x)};
     __builtin_amdgcn_raw_buffer_store_b64(v, r, lane_bytes, uniform_bytes, AUX);
 }
-constexpr int AUX_SC1 = 16; // agent scope: served by the XCD's L2, never by this CU's L1
 
 // Tests a pass flag through an opaque scalar copy: the compiler then cannot tell that two tests
 // of the same flag agree, and does not clone everything between them for each outcome.
@@ -429,19 +439,9 @@ struct Round {
             const __amdgpu_buffer_rsrc_t res = tile_resource(p.data + g.uniform_index());
             const uint32_t lane = (uint32_t)g.lane_index(ss, r0) * 8u;
             const uint32_t stepb = 8u << (g.logT + rstep_log);
-            if (flag_set(p.flags, PASS_COHERENT_LOADS)) {
 #pragma unroll
-                for (int i = 0; i < M; i++)
-                    x[i] = buffer_load64<AUX_SC1>(res, lane, i * stepb);
-            } else if (flag_set(p.flags, PASS_CACHED_STORES)) {
-#pragma unroll
-                for (int i = 0; i < M; i++)
-                    x[i] = buffer_load64<0>(res, lane, i * stepb);
-            } else {
-#pragma unroll
-                for (int i = 0; i < M; i++)
-                    x[i] = buffer_load64(res, lane, i * stepb);
-            }
+            for (int i = 0; i < M; i++)
+                x[i] = buffer_load64(res, lane, i * stepb);
         } else {
             const uint64_t* src = p.data + g.uniform_index() + g.lane_index(ss, r0);
             const uint64_t step = 1ull << (g.logT + rstep_log);
@@ -461,15 +461,9 @@ struct Round {
             const __amdgpu_buffer_rsrc_t res = tile_resource(p.data + g.uniform_index());
             const uint32_t lane = (uint32_t)g.lane_index(sigma, r0) * 8u;
             const uint32_t stepb = 8u << (g.logT + rstep_log);
-            if (flag_set(p.flags, PASS_CACHED_STORES)) {
 #pragma unroll
-                for (int i = 0; i < M; i++)
-                    buffer_store64<0>(res, lane, i * stepb, x[i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < M; i++)
-                    buffer_store64(res, lane, i * stepb, x[i]);
-            }
+            for (int i = 0; i < M; i++)
+                buffer_store64(res, lane, i * stepb, x[i]);
         } else {
             uint64_t* dst = p.data + g.gidx(sigma, r0);
             const uint64_t step = 1ull << (g.logT + rstep_log);
@@ -477,6 +471,11 @@ struct Round {
             for (int i = 0; i < M; i++)
                 dst[i * step] = x[i];
         }
+    }
+    // position of register i in the padded exchange tile
+    __device__ __forceinline__ uint32_t lds_index(int i) const
+    {
+        return lds_addr<CONTIG, K>(sigma, r0 + ((uint32_t)i << rstep_log));
     }
     __device__ __forceinline__ void load_lds(uint64_t (&x)[M], const uint64_t* lds) const
     {
@@ -500,9 +499,7 @@ __device__ __forceinline__ void finish_all(uint64_t (&x)[M], const typename A::C
         for (int i = 0; i < M; i++)
             x[i] = A::finish_lazy(x[i], c);
     } else {
-#pragma unroll
-        for (int i = 0; i < M; i++)
-            x[i] = A::finish(x[i], c);
+        A::template finish_group<M>(x, c);
     }
 }
 
@@ -525,7 +522,7 @@ __device__ __forceinline__ void do_round(const PassParams& p, const TileGeom<K1 
             r.load_global(x, p, g, c);
         else
             r.load_lds(x, lds);
-        if (!(p.flags & PASS_DEBUG_NO_MATH))
+        if (!NTTX_PROF(p.flags & PASS_DEBUG_NO_MATH))
             radix<A, R::KR, FWD>(x, RegTw<A, R::KR>{w}, c, ROUND_A ? scale_mode(p.flags) : SCALE_NONE);
         if (FWD && LAST_OF_PASS && (p.flags & PASS_FINISH))
             finish_all<A, R::M>(x, c, p.flags);
@@ -594,15 +591,10 @@ __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<
     };
     auto present = [&](int i) -> bool { return XB ? (fu(i) >> K) < left : fu(i) + fl < left; };
     const bool buffers = flag_set(p.flags, PASS_OFFSET32);
-    const bool coherent = flag_set(p.flags, PASS_COHERENT_LOADS), cached = flag_set(p.flags, PASS_CACHED_STORES);
     auto load_pair = [&](const uint64_t* from, int i) -> ulonglong2 {
         ulonglong2 v = make_ulonglong2(0, 0);
         if (present(i)) {
-            if (buffers && coherent)
-                v = buffer_load128<AUX_SC1>(tile_resource(from + first), fl * 8, (uint32_t)uniform_elems(i) * 8);
-            else if (buffers && cached)
-                v = buffer_load128<0>(tile_resource(from + first), fl * 8, (uint32_t)uniform_elems(i) * 8);
-            else if (buffers)
+            if (buffers)
                 v = buffer_load128(tile_resource(from + first), fl * 8, (uint32_t)uniform_elems(i) * 8);
             else
                 v = *reinterpret_cast<const ulonglong2*>(from + first + uniform_elems(i) + fl);
@@ -646,9 +638,7 @@ __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<
                 ulonglong2 v;
                 v.x = at[0];
                 v.y = at[1];
-                if (buffers && cached)
-                    buffer_store128<0>(tile_resource(p.data + first), fl * 8, (uint32_t)uniform_elems(i) * 8, v);
-                else if (buffers)
+                if (buffers)
                     buffer_store128(tile_resource(p.data + first), fl * 8, (uint32_t)uniform_elems(i) * 8, v);
                 else
                     *reinterpret_cast<ulonglong2*>(p.data + first + uniform_elems(i) + fl) = v;
@@ -718,9 +708,10 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8, XB
     const RB rb(g, 0);
     uint64_t x[16];
     const int scale = scale_mode(p.flags);
-    const bool math = !(p.flags & PASS_DEBUG_NO_MATH);
-    const bool math_a = math && !(p.flags & PASS_DEBUG_NO_MATH_A), math_b = math && !(p.flags & PASS_DEBUG_NO_MATH_B);
-    const bool twl = !(p.flags & PASS_DEBUG_NO_TW);
+    const bool math = !NTTX_PROF(p.flags & PASS_DEBUG_NO_MATH);
+    const bool math_a = math && !NTTX_PROF(p.flags & PASS_DEBUG_NO_MATH_A);
+    const bool math_b = math && !NTTX_PROF(p.flags & PASS_DEBUG_NO_MATH_B);
+    const bool twl = !NTTX_PROF(p.flags & PASS_DEBUG_NO_TW);
 
     // ---- stage the shared twiddle sets: thread t fetches entry j = t & 15 of set t >> 4 ----
     const uint32_t set = threadIdx.x >> 4, j = threadIdx.x & 15;
@@ -832,11 +823,240 @@ __device__ __forceinline__ void pass_8(const PassParams& p, const TileGeom<8, XB
     }
 }
 
+
+// ---- the 8-stage pass on half the LDS ------------------------------------------------------------
+//
+// pass_8 hands a tile from one register round to the other through a 34 KiB LDS tile; with the
+// twiddle table that is 38.5 KiB per workgroup and four workgroups (16 waves) per CU, whatever the
+// kernels' register counts would allow.  pass_8h does the same work in 21.5 KiB for the two tile
+// kinds the large batches run on (STRIDED, and the cross-batch CONTIG tile: twiddle sets shared by
+// the workgroup in both rounds):
+//   * the exchange between the rounds moves the low 32-bit halves of all 4096 elements through a
+//     17 KiB tile of words, then the high halves through the same tile (exchange_planes): the same
+//     LDS bytes as before in twice as many, half as wide instructions, and two more barriers;
+//   * the cross-batch tile's way to and from HBM with 16 bytes per lane (move_runs) is private to a
+//     wave -- round B leaves each wave with four whole 256-element runs -- and goes through a
+//     4.25 KiB staging area per wave, two runs at a time, with no workgroup barrier.
+constexpr int WAVE_STAGE_ELEMS = 512 + 512 / 16; // two runs of 256 elements, padded like the CONTIG tile
+static_assert(4 * WAVE_STAGE_ELEMS * sizeof(uint64_t) <= LDS_ELEMS * sizeof(uint32_t),
+              "the four waves' staging areas overlay the word tile");
+
+// Register layout `from` -> register layout `to` of the same tile, one 32-bit plane at a time.
+// Called by all threads of the workgroup; nobody may still be using `plane` for something else.
+template <class RFrom, class RTo>
+__device__ __forceinline__ void exchange_planes(uint64_t (&x)[16], const RFrom& from, const RTo& to, uint32_t* plane)
+{
+    uint32_t low[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        plane[from.lds_index(i)] = lo32(x[i]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        low[i] = plane[to.lds_index(i)];
+    __syncthreads(); // every low word has been taken out before a high word lands on it
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        plane[from.lds_index(i)] = hi32(x[i]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        x[i] = pack64(low[i], plane[to.lds_index(i)]);
+}
+
+// Cross-batch tile (16 runs of 256 contiguous elements, run sigma in transform 16 (tile >> s0) + sigma)
+// <-> the registers of round B, for one wave: thread (sigma = 4w + (lane >> 4), rhigh = lane & 15)
+// holds elements 16 rhigh .. 16 rhigh + 15 of run sigma, and HBM is addressed with 16 bytes per lane
+// (step j = 0..7 of a lane: elements 2 lane, 2 lane + 1 of half j & 1 of run 4w + (j >> 1)).  The two
+// meet in the wave's staging area, two runs (steps 4h .. 4h+3, lanes 32h .. 32h+31) at a time.
+// TO_REGS: HBM -> registers, with the input screen and the pointwise product of a first backward
+// pass; otherwise registers -> HBM.
+template <class A, bool TO_REGS>
+__device__ __forceinline__ void move_runs(uint64_t (&x)[16], const PassParams& p, const TileGeom<8, true>& g,
+                                          const typename A::Ctx& c, uint64_t* stage_all)
+{
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t* const stage = stage_all + w * WAVE_STAGE_ELEMS;
+    // first element of the tile in the buffer, distance between runs, runs present (as copy_contig)
+    const uint64_t tau16 = (g.tile >> g.s0) << 4;
+    const uint64_t first = ((tau16 << g.s0) + (g.tile & ((1ull << g.s0) - 1))) << 8;
+    const uint64_t run_stride = 1ull << (g.s0 + 8);
+    const uint64_t runs = (p.nblocks_total >> g.s0) - tau16;
+    const uint32_t left = runs < 16 ? (uint32_t)runs : 16u;
+    const bool buffers = flag_set(p.flags, PASS_OFFSET32);
+    auto run_of = [&](int j) -> uint32_t { return 4 * w + (uint32_t)(j >> 1); };
+    auto uniform_elems = [&](int j) -> uint64_t { return run_of(j) * run_stride + (uint32_t)(j & 1) * 128u; };
+    auto present = [&](int j) -> bool { return run_of(j) < left; };
+    // staging position of element e of the two runs in flight: e + (e >> 4), computed in two parts
+    uint64_t* const lane_at = stage + (2 * lane + (lane >> 3));         // e = 128 jj + 2 lane
+    auto step_at = [&](int jj) -> uint64_t* { return lane_at + jj * 136; };
+    const uint32_t own = ((lane >> 4) & 1) * 256 + (lane & 15) * 16;    // first of this thread's 16 elements
+    uint64_t* const own_at = stage + (own + (own >> 4));
+    const uint32_t own_half = lane >> 5;
+
+    if (TO_REGS) {
+        auto load_all = [&](const uint64_t* from, uint64_t (&t)[16]) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                ulonglong2 v = make_ulonglong2(0, 0);
+                if (present(j)) {
+                    if (buffers)
+                        v = buffer_load128(tile_resource(from + first), lane * 16, (uint32_t)uniform_elems(j) * 8);
+                    else
+                        v = *reinterpret_cast<const ulonglong2*>(from + first + uniform_elems(j) + 2 * lane);
+                }
+                t[2 * j] = v.x;
+                t[2 * j + 1] = v.y;
+            }
+        };
+        uint64_t t[16];
+        load_all(p.data, t);
+        if (p.flags & PASS_CONDITION_INPUT)
+            condition_all<A, 16>(t, c);
+        if (p.flags & PASS_POINTWISE) {
+            uint64_t t2[16];
+            load_all(p.data2, t2);
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                t[i] = A::pointwise(t[i], t2[i], c);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                uint64_t* const at = step_at(jj); // 2 lane is even: both elements share a padding group
+                at[0] = t[2 * (4 * h + jj)];
+                at[1] = t[2 * (4 * h + jj) + 1];
+            }
+            wave_sync();
+            if (own_half == (uint32_t)h) {
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    x[i] = own_at[i];
+            }
+            wave_sync(); // the area is free for the next two runs
+        }
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (own_half == (uint32_t)h) {
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    own_at[i] = x[i];
+            }
+            wave_sync();
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int j = 4 * h + jj;
+                if (present(j)) {
+                    const uint64_t* const at = step_at(jj);
+                    ulonglong2 v;
+                    v.x = at[0];
+                    v.y = at[1];
+                    if (buffers)
+                        buffer_store128(tile_resource(p.data + first), lane * 16, (uint32_t)uniform_elems(j) * 8, v);
+                    else
+                        *reinterpret_cast<ulonglong2*>(p.data + first + uniform_elems(j) + 2 * lane) = v;
+                }
+            }
+            wave_sync();
+        }
+    }
+}
+
+template <class A, bool FWD, bool CONTIG>
+__device__ __forceinline__ void pass_8h(const PassParams& p, const TileGeom<8, CONTIG>& g, const typename A::Ctx& c,
+                                        uint32_t* plane, typename A::TwElem* ldstw)
+{
+    constexpr bool XB = CONTIG; // the only CONTIG tile handled here is the cross-batch one
+    using RA = Round<A, CONTIG, 4, 4, true, XB>;
+    using RB = Round<A, CONTIG, 4, 4, false, XB>;
+    using TwElem = typename A::TwElem;
+    const TwElem* tw = static_cast<const TwElem*>(p.tw);
+    const RA ra(g, 0);
+    const RB rb(g, 0);
+    uint64_t x[16];
+    const int scale = scale_mode(p.flags);
+    const bool math = !NTTX_PROF(p.flags & PASS_DEBUG_NO_MATH);
+    const bool math_a = math && !NTTX_PROF(p.flags & PASS_DEBUG_NO_MATH_A);
+    const bool math_b = math && !NTTX_PROF(p.flags & PASS_DEBUG_NO_MATH_B);
+
+    // twiddles as in pass_8: thread t fetches entry j = t & 15 of round B's set t >> 4, threads
+    // 0..15 also entry t of round A's single set
+    const uint32_t set = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const uint32_t u = 32 - __clz(j | 1);
+    const uint32_t b = j ? j - (1u << (u - 1)) : 0;
+    const uint64_t P0 = g.twiddle_base(0);
+    using Raw = __attribute__((ext_vector_type(sizeof(TwElem) / 4))) uint32_t;
+    const Raw mine = *reinterpret_cast<const Raw*>(tw + ((((P0 << 4) + set) << (u - 1)) + b));
+    const Raw uni = *reinterpret_cast<const Raw*>(tw + ((P0 << (u - 1)) + b));
+    TwElem* const shared_sets = ldstw;
+    TwElem* const uniform_set = ldstw + 16 * TW_SET_STRIDE;
+    auto stage_twiddles = [&]() {
+        reinterpret_cast<Raw*>(shared_sets)[set * TW_SET_STRIDE + j] = mine;
+        if (threadIdx.x < 16)
+            reinterpret_cast<Raw*>(uniform_set)[threadIdx.x] = uni;
+    };
+    const LdsTw<A> set_a{uniform_set, c};
+    const LdsTw<A> set_b{shared_sets + (CONTIG ? (threadIdx.x & 15) : (threadIdx.x >> 4)) * TW_SET_STRIDE, c};
+    uint64_t* const stage = reinterpret_cast<uint64_t*>(plane);
+
+    if (FWD) {
+        ra.load_global(x, p, g, c);
+        stage_twiddles();
+        __syncthreads();
+        if (math_a)
+            radix<A, 4, true>(x, set_a, c, SCALE_NONE);
+        exchange_planes(x, ra, rb, plane);
+        if (math_b)
+            radix<A, 4, true>(x, set_b, c, SCALE_NONE);
+        if (p.flags & PASS_FINISH)
+            finish_all<A, 16>(x, c, p.flags);
+        if constexpr (CONTIG) {
+            __syncthreads(); // every wave has its words out of the planes, which the staging areas overlay
+            move_runs<A, false>(x, p, g, c, stage);
+        } else {
+            rb.store_global(x, p, g);
+        }
+    } else {
+        if constexpr (CONTIG)
+            move_runs<A, true>(x, p, g, c, stage);
+        else
+            rb.load_global(x, p, g, c);
+        stage_twiddles();
+        __syncthreads(); // twiddles staged; every wave is done with its staging area
+        if (math_b)
+            radix<A, 4, false>(x, set_b, c, SCALE_NONE);
+        exchange_planes(x, rb, ra, plane);
+        if (math_a)
+            radix<A, 4, false>(x, set_a, c, scale);
+        ra.store_global(x, p, g);
+    }
+}
+
+// Which pass_kernel shapes run pass_8h, and with how many waves per SIMD the compiler may count.
+#ifndef NTTX_HALF_LDS
+#define NTTX_HALF_LDS 1
+#endif
+#ifndef NTTX_HALF_WAVES
+#define NTTX_HALF_WAVES 4
+#endif
+template <bool CONTIG, int K1, int K2, bool XB>
+constexpr bool half_lds_shape()
+{
+    return NTTX_HALF_LDS && K1 == 4 && K2 == 4 && (!CONTIG || XB);
+}
+template <bool CONTIG, int K1, int K2, bool XB>
+constexpr int pass_waves()
+{
+    return half_lds_shape<CONTIG, K1, K2, XB>() ? NTTX_HALF_WAVES : 4;
+}
+
 template <class A, bool FWD, bool CONTIG, int K1, int K2, bool XB = false>
-__global__ __launch_bounds__(THREADS, 4) void pass_kernel(PassParams p, typename A::Ctx c)
+__global__ __launch_bounds__(THREADS, (pass_waves<CONTIG, K1, K2, XB>())) void pass_kernel(PassParams p, typename A::Ctx c)
 {
     constexpr int K = K1 + K2;
-    __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
     // Workgroups are handed to the 8 XCDs round-robin (id % 8).  With xcd_group = G the tiles are
     // dealt so that each XCD works on runs of G consecutive tiles: workgroup id -> run
     // (id / 8G) * 8 + id % 8, position (id / 8) % G inside it.  The host only sets G when the
@@ -846,14 +1066,20 @@ __global__ __launch_bounds__(THREADS, 4) void pass_kernel(PassParams p, typename
         const uint32_t G = p.xcd_group;
         tile = ((uint64_t)(blockIdx.x / (8 * G)) * 8 + blockIdx.x % 8) * G + (blockIdx.x / 8) % G;
     }
-    if (p.flags & PASS_DEBUG_HOT_TILES)
+    if (NTTX_PROF(p.flags & PASS_DEBUG_HOT_TILES))
         tile &= 63;
     const TileGeom<K, XB> g(p, tile);
 
-    if constexpr (K1 == 4 && K2 == 4) {
+    if constexpr (half_lds_shape<CONTIG, K1, K2, XB>()) {
+        __shared__ __attribute__((aligned(16))) uint32_t plane[LDS_ELEMS];
+        __shared__ __attribute__((aligned(16))) typename A::TwElem ldstw[LDSTW_ELEMS];
+        pass_8h<A, FWD, CONTIG>(p, g, c, plane, ldstw);
+    } else if constexpr (K1 == 4 && K2 == 4) {
+        __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
         __shared__ __attribute__((aligned(16))) typename A::TwElem ldstw[LDSTW_ELEMS];
         pass_8<A, FWD, CONTIG, XB>(p, g, c, lds, ldstw);
     } else if constexpr (CONTIG) {
+        __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
         copy_contig<A, K, true>(p, g, c, lds);
         __syncthreads();
         if constexpr (FWD) {
@@ -872,6 +1098,7 @@ __global__ __launch_bounds__(THREADS, 4) void pass_kernel(PassParams p, typename
         __syncthreads();
         copy_contig<A, K, false>(p, g, c, lds);
     } else {
+        __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
         if constexpr (K2 == 0) {
             do_round<A, FWD, CONTIG, K1, K2, true, true, true>(p, g, c, lds);
         } else if constexpr (FWD) {
@@ -918,7 +1145,7 @@ __global__ __launch_bounds__(THREADS, 4) void fused_small_kernel(PassParams p, t
         const uint32_t f = (uint32_t)gf.lane_index(r.sigma, r.r0 + i);
         return f + (f >> 4);
     };
-    const bool math = !(p.flags & PASS_DEBUG_NO_MATH);
+    const bool math = !NTTX_PROF(p.flags & PASS_DEBUG_NO_MATH);
 
     if (FWD) {
 #pragma unroll
@@ -979,13 +1206,13 @@ __global__ __launch_bounds__(THREADS, 3) void product_mid_kernel(PassParams pf, 
     using TwElem = typename A::TwElem;
     using Raw = __attribute__((ext_vector_type(sizeof(TwElem) / 4))) uint32_t;
     uint64_t tile = blockIdx.x;
-    if (pf.flags & PASS_DEBUG_HOT_TILES)
+    if (NTTX_PROF(pf.flags & PASS_DEBUG_HOT_TILES))
         tile &= 63;
     const TileGeom<8, true> g(pf, tile);
     const RA ra(g, 0);
     const RB rb(g, 0);
     const bool square = pf.data2 == pf.data;
-    const bool math = !(pf.flags & PASS_DEBUG_NO_MATH);
+    const bool math = !NTTX_PROF(pf.flags & PASS_DEBUG_NO_MATH);
 
     // twiddles of both directions, staged as pass_8 stages those of one: thread t fetches entry
     // j = t & 15 of round B's set t >> 4; threads 0..15 also fetch round A's single set
@@ -1052,169 +1279,6 @@ __global__ __launch_bounds__(THREADS, 3) void product_mid_kernel(PassParams pf, 
     if (math)
         radix<A, 4, false>(xa, ba, c, scale_mode(pb.flags));
     ra.store_global(xa, pb, g);
-}
-
-// ---- both passes of a 2^16-point transform in ONE launch ------------------------------------------
-//
-// The two 8-stage passes of n = 2^16 exchange their data through the XCD's L2 instead of HBM: a
-// transform is 16 tiles in either pass, the 16 workgroups that take them (a "team") all run on
-// one XCD, and the second pass of a transform starts as soon as the team's 16 first-pass tiles are
-// stored -- its loads then hit the lines the first pass left in that XCD's L2, and the second
-// pass's stores overwrite them before they are ever written back.  HBM sees one read and one write
-// of the batch per transform instead of two.
-//
-// Scheduling is by tickets, per XCD (the hardware's XCC_ID register, not an assumption about
-// dispatch order): ticket t of an XCD's first-phase counter is tile t mod 16 of that XCD's team
-// t / 16, and likewise for the second phase.  The holder of a team's first ticket claims the team's
-// transform from one global counter (in team order, so a team without a transform is never
-// followed by one with), which also balances the XCDs and makes every placement of workgroups
-// correct, including XCDs that receive none.  A workgroup never blocks before its first-phase tile
-// is stored, and while its second-phase tile waits for the team it takes further first-phase
-// tickets instead of spinning, so every wait ends for any number of resident workgroups.  Every
-// second-phase ticket is preceded by a first-phase ticket of the same workgroup, so the team a
-// second-phase ticket names has always been created.
-//
-// Visibility inside the XCD: first-phase stores use the default policy (they stay in L2); every
-// storing wave drains them (s_waitcnt vmcnt(0)) before the workgroup barrier that precedes the
-// arrival count; second-phase loads carry sc1 (served by L2: a CU's vector L1 is not refreshed by
-// other CUs' stores).  All tiles of a team are on one XCD, whose CUs share that L2.
-struct FusedSync {
-    // all fields are 32-bit counters in device memory, zeroed before each launch
-    uint32_t* ticket1;  // [8][32]: first-phase tickets per XCD (one counter per 128 bytes)
-    uint32_t* ticket2;  // [8][32]: second-phase tickets per XCD
-    uint32_t* next;     // transforms claimed so far
-    uint32_t* arrived;  // [batch]: first-phase tiles stored, per transform
-    uint32_t* team;     // [8][team_stride]: transform of each XCD's team + 1 (0 = not claimed yet)
-    uint32_t team_stride;
-    uint32_t batch;
-};
-
-__device__ __forceinline__ uint32_t relaxed_load(const uint32_t* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Polls until *p != 0.  Every such wait in fused16_kernel is for a running workgroup that does
-// not block before it writes *p; the bound only turns a bug into a trap instead of a hang.
-__device__ __forceinline__ uint32_t wait_nonzero(const uint32_t* p)
-{
-    for (uint32_t spins = 0;; spins++) {
-        const uint32_t v = relaxed_load(p);
-        if (v != 0)
-            return v;
-        __builtin_amdgcn_s_sleep(4);
-        if (spins > (1u << 24))
-            __builtin_trap();
-    }
-}
-
-template <class A, bool FWD>
-__global__ __launch_bounds__(THREADS, 2) void fused16_kernel(PassParams p1, PassParams p2, FusedSync y, typename A::Ctx c)
-{
-    __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
-    __shared__ __attribute__((aligned(16))) typename A::TwElem ldstw[LDSTW_ELEMS];
-    __shared__ uint32_t mail[2];
-    // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4): id 20, offset 0, width 4
-    const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
-    uint32_t* const ticket1 = y.ticket1 + xcc * 32;
-    uint32_t* const ticket2 = y.ticket2 + xcc * 32;
-    uint32_t* const team = y.team + (uint64_t)xcc * y.team_stride;
-    const bool leader = threadIdx.x == 0;
-
-    // value computed by thread 0, handed to the whole workgroup
-    auto broadcast = [&](uint32_t v) -> uint32_t {
-        if (leader)
-            mail[0] = v;
-        __syncthreads();
-        const uint32_t r = mail[0];
-        __syncthreads();
-        return r;
-    };
-    // first-phase ticket -> (transform, tile); transform >= batch: the batch is used up
-    auto first_phase_work = [&](uint32_t& T, uint32_t& m) {
-        uint32_t v = 0, t = 0;
-        if (leader) {
-            t = atomicAdd(ticket1, 1u);
-            const uint32_t k = t >> 4;
-            if ((t & 15u) == 0) {
-                if (k > 0)
-                    (void)wait_nonzero(team + k - 1); // claims go in team order
-                const uint32_t claimed = atomicAdd(y.next, 1u);
-                v = (claimed < y.batch ? claimed : y.batch) + 1;
-                __hip_atomic_store(team + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                v = wait_nonzero(team + k);
-            }
-            mail[1] = t & 15u;
-        }
-        T = broadcast(v) - 1;
-        m = mail[1];
-    };
-
-    bool more_first = true, holding = false;
-    uint32_t T2 = 0, m2 = 0, idle = 0;
-    for (;;) {
-        // ---- a first-phase tile, unless a second-phase tile is ready or the batch is used up ----
-        bool ready = false;
-        if (holding) {
-            uint32_t r = 0;
-            if (leader) {
-                for (int spins = 0; spins < 64 && !r; spins++) {
-                    r = relaxed_load(y.arrived + T2) >= 16u;
-                    if (!r)
-                        __builtin_amdgcn_s_sleep(2);
-                }
-            }
-            ready = broadcast(r) != 0;
-            // nothing left to do but wait for other workgroups' first-phase tiles, which are in
-            // progress; a bound turns a scheduling bug into a trap instead of a hang
-            if (!ready && !more_first && ++idle > (1u << 18))
-                __builtin_trap();
-        }
-        // Also taken, without work to do, before every second-phase ticket once the batch is used up:
-        // second-phase ticket t belongs to the team that first-phase ticket 16 (t >> 4) creates, so
-        // the first-phase counter has to stay ahead of the second-phase one.
-        if (!ready && (more_first || !holding)) {
-            uint32_t T1, m1;
-            first_phase_work(T1, m1);
-            if (T1 < y.batch) {
-                const uint64_t tile = (uint64_t)T1 * 16 + m1;
-                if (FWD)
-                    pass_8<A, true, false, false>(p1, TileGeom<8, false>(p1, tile), c, lds, ldstw);
-                else
-                    pass_8<A, false, true, false>(p1, TileGeom<8, false>(p1, tile), c, lds, ldstw);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores have reached L2
-                __syncthreads();
-                if (leader)
-                    atomicAdd(y.arrived + T1, 1u);
-            } else {
-                more_first = false;
-            }
-        }
-        // ---- a second-phase ticket ----
-        if (!holding) {
-            uint32_t v = 0;
-            if (leader) {
-                const uint32_t t = atomicAdd(ticket2, 1u);
-                v = wait_nonzero(team + (t >> 4)); // claimed by the holder of first-phase ticket 16 (t >> 4) <= t
-                mail[1] = t & 15u;
-            }
-            T2 = broadcast(v) - 1;
-            m2 = mail[1];
-            if (T2 >= y.batch)
-                break; // no transform left for this XCD's teams
-            holding = true;
-            continue;
-        }
-        if (ready) {
-            const uint64_t tile = (uint64_t)T2 * 16 + m2;
-            if (FWD)
-                pass_8<A, true, true, false>(p2, TileGeom<8, false>(p2, tile), c, lds, ldstw);
-            else
-                pass_8<A, false, false, false>(p2, TileGeom<8, false>(p2, tile), c, lds, ldstw);
-            __syncthreads();
-            holding = false;
-        }
-    }
 }
 
 } // namespace nttx

@@ -26,12 +26,6 @@ template <class A>
 hipError_t launch_fused_policy(bool fwd, int kf, const PassParams& p, const typename A::Ctx& c, unsigned grid,
                                hipStream_t s);
 
-// Launches fused16_kernel: both 8-stage passes of n = 2^16 in one launch (p1 / p2: first / second
-// phase in execution order).
-template <class A>
-hipError_t launch_fused16_policy(bool fwd, const PassParams& p1, const PassParams& p2, const FusedSync& y,
-                                 const typename A::Ctx& c, unsigned grid, hipStream_t s);
-
 // Launches product_mid_kernel over `grid` cross-batch tiles: last forward pass of both operands, product,
 // first backward pass (pf / pb: the forward / backward pass parameters).
 template <class A>
@@ -42,8 +36,6 @@ hipError_t launch_product_mid_policy(const PassParams& pf, const PassParams& pb,
     extern template hipError_t launch_pass_policy<A>(bool, const PassDesc&, const PassParams&, const A::Ctx&, unsigned, \
                                                      hipStream_t);                                                    \
     extern template hipError_t launch_fused_policy<A>(bool, int, const PassParams&, const A::Ctx&, unsigned, hipStream_t); \
-    extern template hipError_t launch_fused16_policy<A>(bool, const PassParams&, const PassParams&, const FusedSync&,  \
-                                                        const A::Ctx&, unsigned, hipStream_t);                         \
     extern template hipError_t launch_product_mid_policy<A>(const PassParams&, const PassParams&, const A::Ctx&, unsigned, \
                                                             hipStream_t);
 NTTX_DECLARE_POLICY(Shoup61)

@@ -10,11 +10,15 @@ template <class A, bool FWD, bool CONTIG, int K1, int K2, bool XB = false>
 hipError_t launch_one(const PassParams& p, const typename A::Ctx& c, unsigned grid, hipStream_t s)
 {
     (void)hipGetLastError(); // drop any error an earlier, unrelated call left behind on this thread
+#ifdef NTTX_PROFILING
     // NTTX_DEBUG_EXTRA_LDS=<bytes>: unused dynamic LDS per workgroup, to lower occupancy in experiments
     static const unsigned extra_lds = [] {
         const char* e = std::getenv("NTTX_DEBUG_EXTRA_LDS");
         return e ? (unsigned)std::atol(e) : 0u;
     }();
+#else
+    constexpr unsigned extra_lds = 0;
+#endif
     hipLaunchKernelGGL((pass_kernel<A, FWD, CONTIG, K1, K2, XB>), dim3(grid), dim3(THREADS), extra_lds, s, p, c);
     return hipGetLastError();
 }
@@ -69,18 +73,6 @@ hipError_t launch_fused_policy(bool fwd, int kf, const PassParams& p, const type
 }
 
 template <class A>
-hipError_t launch_fused16_policy(bool fwd, const PassParams& p1, const PassParams& p2, const FusedSync& y,
-                                 const typename A::Ctx& c, unsigned grid, hipStream_t s)
-{
-    (void)hipGetLastError();
-    if (fwd)
-        hipLaunchKernelGGL((fused16_kernel<A, true>), dim3(grid), dim3(THREADS), 0, s, p1, p2, y, c);
-    else
-        hipLaunchKernelGGL((fused16_kernel<A, false>), dim3(grid), dim3(THREADS), 0, s, p1, p2, y, c);
-    return hipGetLastError();
-}
-
-template <class A>
 hipError_t launch_product_mid_policy(const PassParams& pf, const PassParams& pb, const typename A::Ctx& c, unsigned grid,
                                      hipStream_t s)
 {
@@ -93,8 +85,6 @@ hipError_t launch_product_mid_policy(const PassParams& pf, const PassParams& pb,
     template hipError_t launch_pass_policy<A>(bool, const PassDesc&, const PassParams&, const A::Ctx&, unsigned,      \
                                               hipStream_t);                                                          \
     template hipError_t launch_fused_policy<A>(bool, int, const PassParams&, const A::Ctx&, unsigned, hipStream_t);   \
-    template hipError_t launch_fused16_policy<A>(bool, const PassParams&, const PassParams&, const FusedSync&,        \
-                                                 const A::Ctx&, unsigned, hipStream_t);                               \
     template hipError_t launch_product_mid_policy<A>(const PassParams&, const PassParams&, const A::Ctx&, unsigned,   \
                                                      hipStream_t);
 

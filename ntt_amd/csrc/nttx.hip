@@ -194,19 +194,6 @@ struct nttx_plan {
         std::unique_ptr<CopyPool> pool;
     };
     mutable std::vector<std::unique_ptr<HostSlot>> host_slots;
-    // Counters of the one-launch n = 2^16 transform (fused16_kernel), per device: a few sets, used in
-    // turn, each guarded by an event so that a set is zeroed for a new launch only after the launch
-    // that used it last has finished (launches of one plan may be in flight on several streams).
-    struct FusedSlot {
-        static constexpr int SETS = 4;
-        std::mutex lock;
-        uint32_t* sets[SETS] = {};
-        hipEvent_t done[SETS] = {};
-        bool used[SETS] = {};
-        unsigned next = 0;
-        int cus = 0; // compute units of the device
-    };
-    mutable std::vector<std::unique_ptr<FusedSlot>> fused_slots;
 };
 
 namespace {
@@ -296,21 +283,27 @@ int device_slot(const nttx_plan* plan, int device)
 }
 
 // Environment switches, read once.  NTTX_NO_BUFFER_ADDRESSING selects the plain-pointer addressing
-// path of the kernels (an alternative code path the tests cover).  Everything else is a profiling
-// aid and is only looked at when NTTX_DEBUG is set:
+// path of the kernels (an alternative code path the tests cover).  Two tuning knobs that leave the
+// results unchanged are looked at when NTTX_DEBUG is set:
+//   NTTX_XCD_GROUP=<G>         runs of G tiles per XCD on every pass (0 = plain order)
+//   NTTX_CHUNK_MIB=<m>         all passes over m MiB of the batch before the next m MiB
+// The profiling build (-DNTTX_PROFILING: libnttx_prof.so, whose nttx_version() says so) also reads,
+// again only when NTTX_DEBUG is set, the switches that skip work and so produce wrong results:
 //   NTTX_DEBUG_NO_MATH=1|A|B   skip the butterflies (of one register round), keep all traffic
 //   NTTX_DEBUG_NO_TW=1         with NO_MATH: skip the twiddle loads too
 //   NTTX_DEBUG_NO_FINISH=1     skip the canonicalising end of the forward transform
-//   NTTX_DEBUG_HOT_TILES=1     every workgroup works on one of the first 64 tiles (all traffic from L2;
-//                              results are meaningless): the pass time with HBM out of the picture
-//   NTTX_XCD_GROUP=<G>         runs of G tiles per XCD on every pass (0 = plain order)
-//   NTTX_CHUNK_MIB=<m>         all passes over m MiB of the batch before the next m MiB
-// (NTTX_DEBUG_EXTRA_LDS is read next to the launches, in launch_impl.hpp.)
+//   NTTX_DEBUG_HOT_TILES=1     every workgroup works on one of the first 64 tiles (all traffic from L2):
+//                              the pass time with HBM out of the picture
+//   NTTX_DEBUG_EXTRA_LDS=<b>   unused dynamic LDS per workgroup, to lower occupancy (launch_impl.hpp)
+// The shipped library contains none of the latter: no environment makes it return wrong results.
 struct Switches {
-    bool no_buffer = false, no_finish = false;
-    uint32_t debug_flags = 0;
+    bool no_buffer = false;
     long xcd_group = -1;
     size_t chunk_bytes = 0;
+#ifdef NTTX_PROFILING
+    bool no_finish = false;
+    uint32_t debug_flags = 0;
+#endif
 };
 const Switches& switches()
 {
@@ -319,6 +312,13 @@ const Switches& switches()
         s.no_buffer = std::getenv("NTTX_NO_BUFFER_ADDRESSING") != nullptr;
         if (std::getenv("NTTX_DEBUG") == nullptr)
             return s;
+        if (const char* e = std::getenv("NTTX_XCD_GROUP"))
+            s.xcd_group = std::atol(e);
+        if (const char* e = std::getenv("NTTX_CHUNK_MIB")) {
+            const long mib = std::atol(e);
+            s.chunk_bytes = mib <= 0 ? (size_t)0 : (size_t)mib << 20;
+        }
+#ifdef NTTX_PROFILING
         if (const char* e = std::getenv("NTTX_DEBUG_NO_MATH"))
             s.debug_flags |= e[0] == 'A' ? (uint32_t)PASS_DEBUG_NO_MATH_A : e[0] == 'B' ? (uint32_t)PASS_DEBUG_NO_MATH_B
                                                                                         : (uint32_t)PASS_DEBUG_NO_MATH;
@@ -327,12 +327,7 @@ const Switches& switches()
         if (std::getenv("NTTX_DEBUG_HOT_TILES"))
             s.debug_flags |= PASS_DEBUG_HOT_TILES;
         s.no_finish = std::getenv("NTTX_DEBUG_NO_FINISH") != nullptr;
-        if (const char* e = std::getenv("NTTX_XCD_GROUP"))
-            s.xcd_group = std::atol(e);
-        if (const char* e = std::getenv("NTTX_CHUNK_MIB")) {
-            const long mib = std::atol(e);
-            s.chunk_bytes = mib <= 0 ? (size_t)0 : (size_t)mib << 20;
-        }
+#endif
         return s;
     }();
     return v;
@@ -340,10 +335,14 @@ const Switches& switches()
 // The profiling switches that act through pass flags; shared by every launch path.
 void apply_debug_flags(PassParams& p)
 {
+#ifdef NTTX_PROFILING
     const Switches& sw = switches();
     p.flags |= sw.debug_flags;
     if (sw.no_finish)
         p.flags &= ~(uint32_t)PASS_FINISH;
+#else
+    (void)p;
+#endif
 }
 
 // Launches pass `d` with parameters `p` (data, geometry and flags already set) over `tiles` tiles.
@@ -442,98 +441,6 @@ int launch_fused(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, 
     return NTTX_OK;
 }
 
-uint32_t pass_flags(const PassDesc& d, size_t fi, size_t np, bool fwd);
-
-// ---- n = 2^16 in one launch (fused16_kernel) -----------------------------------------------------
-// Largest batch of one fused launch (the counters are sized for it) and the smallest worth one.
-constexpr size_t FUSED16_MAX_BATCH = 1u << 16;
-constexpr size_t FUSED16_MIN_BATCH = 64;
-constexpr unsigned FUSED16_WGS_PER_CU = 2;
-// 32-bit words of one counter set: two ticket arrays, the claim counter, arrivals, teams per XCD
-size_t fused16_words(size_t batch, unsigned grid, uint32_t* team_stride)
-{
-    // teams per XCD: at most one per transform, plus the empty ones created while the batch runs out
-    // (at most two first-phase tickets per workgroup)
-    *team_stride = (uint32_t)(batch + grid / 4 + 16);
-    return 256 + 256 + 32 + batch + 8ull * *team_stride;
-}
-
-bool fused16_applies(const nttx_plan* plan, size_t batch)
-{
-    // Opt-in (NTTX_FUSED16=1).  Measured on MI355X, batch 4096: the second pass's loads do hit L2
-    // (FETCH_SIZE x 2 = 2.17 GB per transform of the batch instead of 4.3 GB) but the L2 writes
-    // through (WRITE_SIZE stays 4.1 GB), and with 178 VGPRs only two workgroups fit a CU, which
-    // cannot hide a tile's latency: 3.7-3.9 ms per direction against 1.6-1.7 ms for the two launches.
-    static const int mode = [] {
-        const char* e = std::getenv("NTTX_FUSED16");
-        return e ? std::atoi(e) : 0;
-    }();
-    return mode != 0 && plan->logn == 16 && batch >= FUSED16_MIN_BATCH && batch <= FUSED16_MAX_BATCH &&
-           !plan->fused_slots.empty();
-}
-
-int launch_fused16(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch, bool fwd, hipStream_t stream, bool lazy)
-{
-    nttx_plan::FusedSlot& fs = *plan->fused_slots[(size_t)slot];
-    const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)fs.cus * FUSED16_WGS_PER_CU, (uint64_t)batch * 16);
-    uint32_t team_stride = 0;
-    const size_t words = fused16_words(batch, grid, &team_stride);
-    // passes in forward order: [0] strided stages 1-8, [1] contiguous stages 9-16
-    const PassDesc& strided = plan->split_passes[0];
-    const PassDesc& contig = plan->split_passes[1];
-    auto params = [&](const PassDesc& d, size_t fi) {
-        PassParams p{};
-        p.data = dptr;
-        p.tw = fwd ? plan->d_fwd[slot] : plan->d_inv[slot];
-        p.tw_perm = fwd ? plan->d_fwd_perm[slot] : plan->d_inv_perm[slot];
-        p.nblocks_total = (uint64_t)batch << d.s0;
-        p.block_base = 0;
-        p.logB = plan->logn - d.s0;
-        p.s0 = d.s0;
-        p.flags = pass_flags(d, fi, 2, fwd) | (lazy ? (uint32_t)PASS_LAZY : 0u);
-        if (!switches().no_buffer)
-            p.flags |= PASS_OFFSET32;
-        apply_debug_flags(p);
-        return p;
-    };
-    PassParams ps = params(strided, 0), pc = params(contig, 1);
-    PassParams& p1 = fwd ? ps : pc;
-    PassParams& p2 = fwd ? pc : ps;
-    p1.flags |= PASS_CACHED_STORES;
-    p2.flags |= PASS_COHERENT_LOADS;
-
-    std::lock_guard<std::mutex> guard(fs.lock);
-    const unsigned set = fs.next++ % nttx_plan::FusedSlot::SETS;
-    if (fs.used[set])
-        HIP_TRY(hipStreamWaitEvent(stream, fs.done[set], 0)); // the launch that used this set last
-    uint32_t* w = fs.sets[set];
-    HIP_TRY(hipMemsetAsync(w, 0, words * sizeof(uint32_t), stream));
-    FusedSync y{};
-    y.ticket1 = w;
-    y.ticket2 = w + 256;
-    y.next = w + 512;
-    y.arrived = w + 544;
-    y.team = w + 544 + batch;
-    y.team_stride = team_stride;
-    y.batch = (uint32_t)batch;
-    hipError_t e;
-    switch (plan->policy) {
-    case nttx_plan::GOLDILOCKS: e = launch_fused16_policy<Goldilocks>(fwd, p1, p2, y, plan->gctx, grid, stream); break;
-    case nttx_plan::GOLDILOCKS_CANONICAL:
-        e = launch_fused16_policy<GoldilocksCanonical>(fwd, p1, p2, y, plan->gctx, grid, stream);
-        break;
-    case nttx_plan::MONT_WIDE: e = launch_fused16_policy<Mont<true>>(fwd, p1, p2, y, plan->mctx, grid, stream); break;
-    case nttx_plan::MONT: e = launch_fused16_policy<Mont<false>>(fwd, p1, p2, y, plan->mctx, grid, stream); break;
-    case nttx_plan::SHOUP61_NEAR: e = launch_fused16_policy<Shoup61Near>(fwd, p1, p2, y, plan->sctx, grid, stream); break;
-    default: e = launch_fused16_policy<Shoup61>(fwd, p1, p2, y, plan->sctx, grid, stream); break;
-    }
-    if (e != hipSuccess)
-        return fail(NTTX_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    HIP_TRY(hipEventRecord(fs.done[set], stream));
-    fs.used[set] = true;
-    return NTTX_OK;
-}
-
 // Flags of the pass at forward-order position `fi` of `np` when running direction `fwd`.
 uint32_t pass_flags(const PassDesc& d, size_t fi, size_t np, bool fwd)
 {
@@ -556,8 +463,6 @@ int enqueue_passes(const nttx_plan* plan, int slot, uint64_t* dptr, size_t batch
                    int only_pass, const uint64_t* mul_with, bool lazy)
 {
     static const bool no_xb = std::getenv("NTTX_NO_CROSS_BATCH") != nullptr;
-    if (only_pass < 0 && mul_with == nullptr && fused16_applies(plan, batch))
-        return launch_fused16(plan, slot, dptr, batch, fwd, stream, lazy);
     const size_t np = plan->passes.size();
     for (size_t i = 0; i < np; i++) {
         if (only_pass >= 0 && (size_t)only_pass != i)
@@ -811,7 +716,7 @@ int run_distributed(const nttx_plan* plan, uint64_t* host, bool fwd, int n_shard
     return rc;
 }
 
-// Optional chunking of a batch (NTTX_DEBUG + NTTX_CHUNK_MIB=<m>): all passes run over m MiB of the
+// Optional chunking of a batch (NTTX_DEBUG=1 NTTX_CHUNK_MIB=<m>): all passes run over m MiB of the
 // batch before the next m MiB, so that a pass re-reads what the previous one wrote while it may
 // still sit in the 256 MiB Infinity Cache.  Measured on MI355X this gains nothing at 256 MiB and
 // loses at smaller chunks (more launch boundaries and partial waves of workgroups), so the default
@@ -1280,24 +1185,8 @@ int finish_plan(nttx_plan* plan, const TableSource& src, const int* devices, int
     plan->d_inv.assign(nd, nullptr);
     plan->d_fwd_perm.assign(nd, nullptr);
     plan->d_inv_perm.assign(nd, nullptr);
-    plan->fused_slots.clear();
-    if (plan->logn == 16)
-        for (size_t i = 0; i < nd; i++)
-            plan->fused_slots.emplace_back(new nttx_plan::FusedSlot);
     for (size_t i = 0; i < nd; i++) {
         HIP_TRY(hipSetDevice(plan->devices[i]));
-        if (plan->logn == 16) {
-            nttx_plan::FusedSlot& fs = *plan->fused_slots[i];
-            hipDeviceProp_t prop;
-            HIP_TRY(hipGetDeviceProperties(&prop, plan->devices[i]));
-            fs.cus = prop.multiProcessorCount;
-            uint32_t stride = 0;
-            const size_t words = fused16_words(FUSED16_MAX_BATCH, (unsigned)fs.cus * FUSED16_WGS_PER_CU, &stride);
-            for (int k = 0; k < nttx_plan::FusedSlot::SETS; k++) {
-                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&fs.sets[k]), words * sizeof(uint32_t)));
-                HIP_TRY(hipEventCreateWithFlags(&fs.done[k], hipEventDisableTiming));
-            }
-        }
         HIP_TRY(hipMalloc(&plan->d_fwd_perm[i], bytes));
         HIP_TRY(hipMalloc(&plan->d_inv_perm[i], bytes));
         for (int dir = 0; dir < 2; dir++) {
@@ -1630,14 +1519,6 @@ void nttx_plan_destroy(nttx_plan* plan)
             (void)hipFree(plan->d_fwd_perm[i]);
         if (i < plan->d_inv_perm.size() && plan->d_inv_perm[i])
             (void)hipFree(plan->d_inv_perm[i]);
-        if (i < plan->fused_slots.size() && plan->fused_slots[i]) {
-            for (int k = 0; k < nttx_plan::FusedSlot::SETS; k++) {
-                if (plan->fused_slots[i]->sets[k])
-                    (void)hipFree(plan->fused_slots[i]->sets[k]);
-                if (plan->fused_slots[i]->done[k])
-                    (void)hipEventDestroy(plan->fused_slots[i]->done[k]);
-            }
-        }
         if (i < plan->host_slots.size() && plan->host_slots[i]) {
             if (plan->host_slots[i]->stream)
                 (void)hipStreamDestroy(plan->host_slots[i]->stream);
@@ -1909,6 +1790,55 @@ int nttx_run_pass_device(const nttx_plan* plan, int device, void* dptr, size_t b
     return run_device(plan, device, dptr, batch, hip_stream, dir == 0, pass_index);
 }
 
+} // extern "C"
+
+namespace {
+// One wave: elapsed shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) over a spin of
+// `ticks` ticks.  The loop ends on the tick count or after a fixed number of polls, whichever
+// comes first, so the wave finishes whatever the counters do.
+__global__ void clock_probe_kernel(uint64_t* out2, uint64_t ticks)
+{
+    if (threadIdx.x != 0)
+        return;
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
+    const uint64_t c0 = __builtin_amdgcn_s_memtime();
+    uint64_t r = r0;
+    for (uint32_t polls = 0; polls < (1u << 26) && r - r0 < ticks; polls++) {
+        __builtin_amdgcn_s_sleep(8);
+        r = __builtin_amdgcn_s_memrealtime();
+    }
+    const uint64_t c1 = __builtin_amdgcn_s_memtime();
+    out2[0] = c1 - c0;
+    out2[1] = r - r0;
+}
+} // namespace
+
+extern "C" {
+
+int nttx_clock_probe_device(int device, uint64_t* out2, int spin_us, void* hip_stream)
+{
+    if (!out2)
+        return fail(NTTX_EINVAL, "out2 is NULL");
+    if (spin_us < 1 || spin_us > 100000)
+        return fail(NTTX_EINVAL, "spin_us must be in [1, 100000]");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
+        return fail(NTTX_ENODEV, "device index out of range");
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != device)
+        HIP_TRY(hipSetDevice(device));
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(hip_stream), out2,
+                       (uint64_t)spin_us * 100);
+    const hipError_t e = hipGetLastError();
+    if (cur != device && cur >= 0)
+        (void)hipSetDevice(cur);
+    if (e != hipSuccess)
+        return fail(NTTX_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return NTTX_OK;
+}
+
 int nttx_forward_distributed(const nttx_plan* plan, uint64_t* host_data, int n_shards)
 {
     return guarded([&] { return run_distributed(plan, host_data, true, n_shards); });
@@ -1966,6 +1896,13 @@ int nttx_device_count(void)
 }
 
 const char* nttx_last_error(void) { return g_err.c_str(); }
-const char* nttx_version(void) { return "nttx 0.2 (gfx950)"; }
+const char* nttx_version(void)
+{
+#ifdef NTTX_PROFILING
+    return "nttx 0.3 (gfx950) PROFILING BUILD: honours NTTX_DEBUG_* switches that produce wrong results";
+#else
+    return "nttx 0.3 (gfx950)";
+#endif
+}
 
 } // extern "C"

@@ -91,8 +91,8 @@ class _PlanTable(DFT):
         """Name of the arithmetic the plan's kernels use (nttx_plan_policy)."""
         return lib.nttx_plan_policy(self._plan).decode()
 
-    def _run(self, x, forward, lazy=False):
-        if lazy:
+    def _run(self, x, forward, range_2q=False):
+        if range_2q:
             host_fn = lib.nttx_forward_host_lazy if forward else lib.nttx_backward_host_lazy
             dev_fn = lib.nttx_forward_device_lazy if forward else lib.nttx_backward_device_lazy
         else:
@@ -126,20 +126,30 @@ class _PlanTable(DFT):
     def backward_inplace(self, x):
         self._run(x, False)
 
-    # ntt.rs:31-35, 45-49: "elements in [0, 2q)".  The reference never reads its LAZY parameter, so
-    # it returns canonical residues here too; this engine skips the last conditional subtractions
-    # where its arithmetic is lazy (q < 2^61) and returns the canonical residues otherwise.
+    # ntt.rs:31-35, 45-49 document "elements in [0, 2q)" for the lazy methods, but the reference never
+    # reads its LAZY parameter (ntt.rs:122, 178; ntt_avx2.rs:108, 281; ntt_goldilock.rs:81, 128): they
+    # return exactly what the strict methods return.  So do these, bit for bit -- a caller ported from
+    # the reference may compare, serialise or REDC-multiply those outputs as canonical residues.
     def forward_inplace_lazy(self, x):
-        self._run(x, True, lazy=True)
+        self._run(x, True)
 
     def backward_inplace_lazy(self, x):
-        self._run(x, False, lazy=True)
+        self._run(x, False)
 
-    def forward_inplace_core(self, x, lazy=False):
-        self._run(x, True, lazy)
+    def forward_inplace_core(self, x, lazy=False):  # `lazy` is accepted and ignored, as in the reference
+        self._run(x, True)
 
     def backward_inplace_core(self, x, lazy=False):
-        self._run(x, False, lazy)
+        self._run(x, False)
+
+    # Explicit opt-in, no counterpart in the reference: outputs in [0, 2q), congruent to the canonical
+    # ones (nttx_*_lazy).  For q < 2^61 the last conditional subtraction is skipped; other plans
+    # return the canonical residues.  Such outputs are valid inputs of every transform here.
+    def forward_inplace_range_2q(self, x):
+        self._run(x, True, range_2q=True)
+
+    def backward_inplace_range_2q(self, x):
+        self._run(x, False, range_2q=True)
 
     # batched host path (no counterpart in the reference, which loops over slices)
     def forward_inplace_batch(self, x, batch):

@@ -70,13 +70,14 @@ class PlanHolder {
 
 // Length semantics: the reference sizes the transform by the slice (ntt.rs:123), but only
 // len == n round-trips (ntt.rs:231-235) and len > n indexes out of bounds (ntt.rs:143).
-// lazy: outputs in [0, 2q) as the reference documents for its *_lazy methods (ntt.rs:31-35, 45-49)
-inline void run(const nttx_plan* plan, uint64_t n, void* x, size_t len, bool forward, bool lazy = false)
+// range_2q: outputs in [0, 2q) (nttx_*_lazy) instead of canonical residues -- an explicit opt-in; the
+// trait's lazy methods return the strict outputs, as the reference's do
+inline void run(const nttx_plan* plan, uint64_t n, void* x, size_t len, bool forward, bool range_2q = false)
 {
     if (len != n)
         throw Panic("slice length does not match the table size");
     uint64_t* a = static_cast<uint64_t*>(x);
-    if (lazy)
+    if (range_2q)
         check(forward ? nttx_forward_host_lazy(plan, a, 1) : nttx_backward_host_lazy(plan, a, 1));
     else
         check(forward ? nttx_forward_host(plan, a, 1) : nttx_backward_host(plan, a, 1));
@@ -154,12 +155,16 @@ class Table<uint64_t> : public DFT<uint64_t> {
     void backward_inplace(uint64_t* a, size_t len) const override { backward_inplace_core<false>(a, len); }    // ntt.rs:41-43
     void backward_inplace_lazy(uint64_t* a, size_t len) const override { backward_inplace_core<true>(a, len); } // ntt.rs:48-50
 
-    // ntt.rs:122, 178.  The reference accepts LAZY and ignores it; here it selects the entry points
-    // whose outputs lie in [0, 2q), the range its lazy methods document (ntt.rs:31-35, 45-49)
+    // ntt.rs:122, 178.  The reference accepts LAZY and never reads it, so its lazy methods return the
+    // strict outputs; the same here, bit for bit.
     template <bool LAZY>
-    void forward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true, LAZY); }
+    void forward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true); }
     template <bool LAZY>
-    void backward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false, LAZY); }
+    void backward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false); }
+    // Explicit opt-in with no counterpart in the reference: outputs in [0, 2q), the range its lazy
+    // methods document (ntt.rs:31-35, 45-49), congruent to the canonical ones (nttx_*_lazy).
+    void forward_inplace_range_2q(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true, true); }
+    void backward_inplace_range_2q(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false, true); }
 
     void forward_inplace_distributed(uint64_t* a, size_t len, int n_shards = 0) const
     {
@@ -229,10 +234,13 @@ class TableAVX2 : public DFT<int64_t> {
     void backward_inplace(int64_t* a, size_t len) const override { backward_inplace_core<false>(a, len); }
     void backward_inplace_lazy(int64_t* a, size_t len) const override { backward_inplace_core<true>(a, len); }
 
+    template <bool LAZY> // never read by the reference (ntt_avx2.rs:108, 281): lazy == strict
+    void forward_inplace_core(int64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true); }   // :108
     template <bool LAZY>
-    void forward_inplace_core(int64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true, LAZY); }   // :108
-    template <bool LAZY>
-    void backward_inplace_core(int64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false, LAZY); } // :281
+    void backward_inplace_core(int64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false); } // :281
+    // opt-in, no counterpart in the reference: outputs in [0, 2q) (nttx_*_lazy)
+    void forward_inplace_range_2q(int64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true, true); }
+    void backward_inplace_range_2q(int64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false, true); }
 
     void forward_inplace_distributed(int64_t* a, size_t len, int n_shards = 0) const
     {
@@ -307,10 +315,10 @@ class TableGoldilock<uint64_t> : public DFT<uint64_t> {
     void backward_inplace(uint64_t* a, size_t len) const override { backward_inplace_core<false>(a, len); }
     void backward_inplace_lazy(uint64_t* a, size_t len) const override { backward_inplace_core<true>(a, len); }
 
+    template <bool LAZY> // never read by the reference (ntt_goldilock.rs:81, 128): lazy == strict
+    void forward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true); }   // :81
     template <bool LAZY>
-    void forward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, true, LAZY); }   // :81
-    template <bool LAZY>
-    void backward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false, LAZY); } // :128
+    void backward_inplace_core(uint64_t* a, size_t len) const { detail::run(plan_.get(), n_, a, len, false); } // :128
 
     void forward_inplace_distributed(uint64_t* a, size_t len, int n_shards = 0) const
     {

@@ -50,6 +50,8 @@ extern "C" {
     pub fn nttx_pass_describe(plan: *const NttxPlan, dir: c_int, pass_index: c_int, buf: *mut c_char, buf_len: usize) -> c_int;
     pub fn nttx_run_pass_device(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, dir: c_int,
                                 pass_index: c_int, hip_stream: *mut c_void) -> c_int;
+    /// {shader cycles, 100 MHz ticks} of a one-wave spin of spin_us microseconds, into device memory out2.
+    pub fn nttx_clock_probe_device(device: c_int, out2: *mut u64, spin_us: c_int, hip_stream: *mut c_void) -> c_int;
     pub fn nttx_forward_distributed(plan: *const NttxPlan, host_data: *mut u64, n_shards: c_int) -> c_int;
     pub fn nttx_backward_distributed(plan: *const NttxPlan, host_data: *mut u64, n_shards: c_int) -> c_int;
     pub fn nttx_shard_geometry(plan: *const NttxPlan, n_shards: c_int, local_elems: *mut u64, rows: *mut u64,

@@ -97,6 +97,85 @@ static void shoup_mul_bounds(uint64_t q)
     }
 }
 
+
+// Scaling by 2^-k without a quotient (mul_pow2_inv) and the group forms that hide the last
+// conditional subtraction behind one comparison (gs_last_stage, finish_group): for every input,
+// including those built to land at q or above before the screen, the results are the canonical
+// residues the one-at-a-time routines give.
+template <bool NEAR>
+static void shoup_group_forms(uint64_t q, uint32_t k)
+{
+    using A = Shoup61T<NEAR>;
+    std::mt19937_64 rng(q + k);
+    const uint64_t n_inv = ntt::utils::mod_exp_u64(ntt::utils::mod_exp_u64(2, k, q), q - 2, q); // 2^-k (q prime here)
+    const uint64_t s1 = rng() % q;
+    const Shoup61Ctx c = make_shoup_ctx(q, n_inv, s1);
+    CHECK(c.scale_shift == k);
+    Shoup61Ctx general = c; // the same constants through the product by a quotient
+    general.scale_shift = 0;
+    const uint64_t two_k = 1ull << k;
+    for (int it = 0; it < 300000; it++) {
+        // x * 2^-k for x below 8q (a sum of two values below 4q): random, edges, and the largest
+        // inputs, whose results reach past q; the result stays below q + x / 2^k < 2q
+        const uint64_t top = 8 * q - 1; // q < 2^61
+        uint64_t x = rng() % top;
+        if (it % 4 == 1)
+            x = (uint64_t[]){0, 1, two_k - 1, two_k, q - 1, q, q + 1, 4 * q, top - 1, top}[rng() % 10];
+        if (it % 4 == 2)
+            x = top - (rng() % (two_k << 3));
+        const uint64_t r = A::mul_pow2_inv(x, c);
+        CHECK(r < 2 * q);
+        CHECK(r % q == mulmod(x % q, n_inv, q));
+    }
+    // whole groups: 16 registers, pairs (i, i + 8)
+    int slow = 0;
+    for (int it = 0; it < 100000; it++) {
+        uint64_t x[16], want[16], y[16];
+        for (int i = 0; i < 16; i++)
+            x[i] = rng() % (4 * q);
+        if (it % 8 == 0) { // sums at the top of the range: mul_pow2_inv overshoots q for some of these
+            x[0] = 4 * q - 1 - rng() % 1000;
+            x[8] = 4 * q - 1 - rng() % 1000;
+        }
+        if (it % 8 == 1) { // a difference of zero and a sum of zero
+            x[1] = x[9] = rng() % (4 * q);
+            x[2] = x[10] = 0;
+        }
+        const typename A::Tw unused = A::make(TwPair{1, 0});
+        for (int i = 0; i < 8; i++) {
+            want[i] = mulmod((uint64_t)(((u128)x[i] + x[i + 8]) % q), n_inv, q);
+            want[i + 8] = mulmod((uint64_t)(((u128)x[i] + 4 * (u128)q - x[i + 8]) % q), s1, q);
+        }
+        for (int i = 0; i < 16; i++) y[i] = x[i];
+        A::template gs_last_stage<16>(y, unused, c);
+        for (int i = 0; i < 16; i++) CHECK(y[i] == want[i]);
+        for (int i = 0; i < 16; i++) y[i] = x[i];
+        A::template gs_last_stage<16>(y, unused, general);
+        for (int i = 0; i < 16; i++) CHECK(y[i] == want[i]);
+        for (int i = 0; i < 8; i++) { // one at a time, both contexts
+            uint64_t a = x[i], b = x[i + 8];
+            A::gs_last(a, b, unused, c);
+            CHECK(a == want[i] && b == want[i + 8]);
+            a = x[i]; b = x[i + 8];
+            A::gs_last(a, b, unused, general);
+            CHECK(a == want[i] && b == want[i + 8]);
+        }
+        // end of the forward transform: any u64 (NEAR) / [0, 8q) (general); every fourth group holds a
+        // value that fold61 leaves at q or above (a multiple of 2^61 minus less than 7 c8, top bits set)
+        for (int i = 0; i < 16; i++)
+            x[i] = NEAR ? rng() : rng() % (8 * q);
+        if (NEAR && it % 4 == 0) {
+            const uint64_t kk = 1 + rng() % 7;
+            x[rng() % 16] = (kk << 61) - 1 - rng() % (kk * c.c8);
+            slow++;
+        }
+        for (int i = 0; i < 16; i++) y[i] = x[i];
+        A::template finish_group<16>(y, c);
+        for (int i = 0; i < 16; i++) CHECK(y[i] == x[i] % q);
+    }
+    (void)slow;
+}
+
 // Whole transform with a policy, radix-2, reference loop order; tables in the policy's format.
 template <class A>
 static void forward(std::vector<uint64_t>& a, const std::vector<typename A::TwElem>& tw, const typename A::Ctx& c)
@@ -305,6 +384,12 @@ int main()
     shoup_butterfly_bounds<true>((1ull << 61) - 1);
     shoup_butterfly_bounds<true>((1ull << 61) - (1ull << 29) + 1); // the smallest modulus the NEAR forms take
     shoup_butterfly_bounds<false>(7681);
+    shoup_group_forms<true>(q61, 16);
+    shoup_group_forms<false>(q61, 16);
+    shoup_group_forms<true>(q61, 12);
+    shoup_group_forms<true>(q61, 20);
+    shoup_group_forms<false>(4293918721ull, 16);
+    shoup_group_forms<false>(998244353ull, 10);
     for (size_t n : {4, 16, 256, 4096}) {
         transform_tests(q61, ntt::utils::mod_exp_u64(psi61, (1 << 16) / n, q61), n);
         transform_tests(Goldilocks::Q, ntt::utils::mod_exp_u64(0xabd0a6e8aa3d8a0eull, (1 << 16) / n, Goldilocks::Q), n);
