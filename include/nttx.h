@@ -141,7 +141,8 @@ int nttx_backward_device(const nttx_plan *plan, int device, void *dptr, size_t b
  * nttx_forward_host / nttx_backward_host bit for bit.  batch * n * 8 bytes must not exceed 32 MiB
  * (64 vectors of 2^16, one of 2^22): larger calls fail with NTTX_EINVAL.  Every call on a GPU
  * shares that GPU's array -- the upload overwrites whatever the last call left there, nothing needs
- * clearing -- so calls that overlap in time on one GPU (from any thread or plan) race; serialise them.
+ * clearing -- so two calls in flight on one GPU would race on it: the library takes a per-device lock
+ * for the whole call, which makes calls from several threads or plans of one process take turns.
  */
 int nttx_transform_host_noalloc(const nttx_plan *plan, uint64_t *data, size_t batch, int dir);
 

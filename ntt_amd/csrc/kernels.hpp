@@ -115,7 +115,10 @@ struct LdsTw { // one 16-entry set staged in LDS, read where it is used
 // A policy with DEFERRED_CHECK computes a stage with its fast butterflies, which report whether
 // any of them may deviate from the strict rules; the stage is then redone strictly from its
 // inputs.  One branch per stage keeps the 2^(K-1) independent butterflies interleavable.
-template <class A, int K, bool FWD, class Src>
+//
+// GROUPED: the last inverse stage in its whole-group form (gs_last_stage: one screen for all outputs);
+// the generic rounds, which also keep their twiddles in registers, take the one-at-a-time form.
+template <class A, int K, bool FWD, class Src, bool GROUPED = true>
 __device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const Src& w, const typename A::Ctx& c, int scale)
 {
     constexpr int M = 1 << K;
@@ -226,8 +229,12 @@ __device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const Src& w, const
 #pragma unroll
                 for (int i = 0; i < half; i++)
                     A::gs_last_lazy(x[i], x[i + half], s, c);
-            } else {
+            } else if (GROUPED) {
                 A::template gs_last_stage<M>(x, s, c);
+            } else {
+#pragma unroll
+                for (int i = 0; i < half; i++)
+                    A::gs_last(x[i], x[i + half], s, c);
             }
         } else {
 #pragma unroll
@@ -491,15 +498,19 @@ struct Round {
     }
 };
 
-template <class A, int M>
+template <class A, int M, bool GROUPED = true>
 __device__ __forceinline__ void finish_all(uint64_t (&x)[M], const typename A::Ctx& c, uint32_t flags)
 {
     if (A::HAS_LAZY && flag_set(flags, PASS_LAZY)) {
 #pragma unroll
         for (int i = 0; i < M; i++)
             x[i] = A::finish_lazy(x[i], c);
-    } else {
+    } else if (GROUPED) {
         A::template finish_group<M>(x, c);
+    } else {
+#pragma unroll
+        for (int i = 0; i < M; i++)
+            x[i] = A::finish(x[i], c);
     }
 }
 
@@ -523,9 +534,9 @@ __device__ __forceinline__ void do_round(const PassParams& p, const TileGeom<K1 
         else
             r.load_lds(x, lds);
         if (!NTTX_PROF(p.flags & PASS_DEBUG_NO_MATH))
-            radix<A, R::KR, FWD>(x, RegTw<A, R::KR>{w}, c, ROUND_A ? scale_mode(p.flags) : SCALE_NONE);
+            radix<A, R::KR, FWD, RegTw<A, R::KR>, false>(x, RegTw<A, R::KR>{w}, c, ROUND_A ? scale_mode(p.flags) : SCALE_NONE);
         if (FWD && LAST_OF_PASS && (p.flags & PASS_FINISH))
-            finish_all<A, R::M>(x, c, p.flags);
+            finish_all<A, R::M, false>(x, c, p.flags);
         if (DST_G)
             r.store_global(x, p, g);
         else
@@ -866,9 +877,10 @@ __device__ __forceinline__ void exchange_planes(uint64_t (&x)[16], const RFrom& 
 
 // Cross-batch tile (16 runs of 256 contiguous elements, run sigma in transform 16 (tile >> s0) + sigma)
 // <-> the registers of round B, for one wave: thread (sigma = 4w + (lane >> 4), rhigh = lane & 15)
-// holds elements 16 rhigh .. 16 rhigh + 15 of run sigma, and HBM is addressed with 16 bytes per lane
-// (step j = 0..7 of a lane: elements 2 lane, 2 lane + 1 of half j & 1 of run 4w + (j >> 1)).  The two
-// meet in the wave's staging area, two runs (steps 4h .. 4h+3, lanes 32h .. 32h+31) at a time.
+// holds elements 16 rhigh .. 16 rhigh + 15 of run sigma, and HBM is addressed with lane-contiguous
+// accesses (stores: 16 bytes per lane, step j = 0..7: elements 2 lane, 2 lane + 1 of half j & 1 of run
+// 4w + (j >> 1); loads: 8 bytes per lane, see below).  The two meet in the wave's staging area, two runs
+// (lanes 32h .. 32h+31 of round B) at a time.
 // TO_REGS: HBM -> registers, with the input screen and the pointwise product of a first backward
 // pass; otherwise registers -> HBM.
 template <class A, bool TO_REGS>
@@ -896,18 +908,19 @@ __device__ __forceinline__ void move_runs(uint64_t (&x)[16], const PassParams& p
     const uint32_t own_half = lane >> 5;
 
     if (TO_REGS) {
+        // Loads take 8 bytes per lane (step j = 0..15: element 64 (j & 3) + lane of run 4w + (j >> 2), 512
+        // contiguous bytes per wave instruction): measured on this tile shape, 16-byte-per-lane loads reach
+        // 4.8 TB/s where these reach 5.9 (tools/ubench_tiles.hip); stores show no such difference.  A run
+        // past the end of the buffer reads the tile's first run instead (always present) and is never stored.
         auto load_all = [&](const uint64_t* from, uint64_t (&t)[16]) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                ulonglong2 v = make_ulonglong2(0, 0);
-                if (present(j)) {
-                    if (buffers)
-                        v = buffer_load128(tile_resource(from + first), lane * 16, (uint32_t)uniform_elems(j) * 8);
-                    else
-                        v = *reinterpret_cast<const ulonglong2*>(from + first + uniform_elems(j) + 2 * lane);
-                }
-                t[2 * j] = v.x;
-                t[2 * j + 1] = v.y;
+            for (int j = 0; j < 16; j++) {
+                const uint32_t run = 4 * w + (uint32_t)(j >> 2);
+                const uint64_t u = (run < left ? run : 0u) * run_stride + (uint32_t)(j & 3) * 64u;
+                if (buffers)
+                    t[j] = buffer_load64(tile_resource(from + first), lane * 8, (uint32_t)u * 8);
+                else
+                    t[j] = from[first + u + lane];
             }
         };
         uint64_t t[16];
@@ -921,14 +934,12 @@ __device__ __forceinline__ void move_runs(uint64_t (&x)[16], const PassParams& p
             for (int i = 0; i < 16; i++)
                 t[i] = A::pointwise(t[i], t2[i], c);
         }
+        uint64_t* const lane8_at = stage + (lane + (lane >> 4)); // element 64 jj + lane of the two runs in flight
 #pragma unroll
         for (int h = 0; h < 2; h++) {
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                uint64_t* const at = step_at(jj); // 2 lane is even: both elements share a padding group
-                at[0] = t[2 * (4 * h + jj)];
-                at[1] = t[2 * (4 * h + jj) + 1];
-            }
+            for (int jj = 0; jj < 8; jj++)
+                lane8_at[jj * 68] = t[8 * h + jj]; // 64 jj + ((64 jj) >> 4)
             wave_sync();
             if (own_half == (uint32_t)h) {
 #pragma unroll

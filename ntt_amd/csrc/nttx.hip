@@ -1232,8 +1232,11 @@ int finish_plan(nttx_plan* plan, const TableSource& src, const int* devices, int
         HIP_TRY(hipDeviceSynchronize());
     }
     // The split transform exchanges pieces between the plan's devices: let them reach each other's
-    // memory directly over xGMI where the topology allows it (otherwise peer copies are staged).
-    for (size_t i = 0; i < nd; i++) {
+    // memory directly over xGMI where the topology allows it (otherwise peer copies are staged by the
+    // runtime).  NTTX_NO_PEER_ACCESS=1 leaves peer access off, which forces the staged form on any
+    // topology (an alternative path for tests on multi-GPU hosts).
+    static const bool no_peer = std::getenv("NTTX_NO_PEER_ACCESS") != nullptr;
+    for (size_t i = 0; i < nd && !no_peer; i++) {
         for (size_t j = 0; j < nd; j++) {
             int can = 0;
             if (i == j || hipDeviceCanAccessPeer(&can, plan->devices[i], plan->devices[j]) != hipSuccess || !can)
@@ -1335,6 +1338,38 @@ int check_plan_arguments(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t 
     return NTTX_OK;
 }
 
+// Entry 0 of both tables is the unit in the table's form (ntt.rs:247-253: the chain starts from
+// transform(1); ntt_goldilock.rs:200-206: from 1); entries 1 are psi^(n/2) and its inverse; n_inv * n
+// is the unit.  A table of another modulus, form or root pair -- or a psi that is not a primitive
+// 2n-th root -- fails these.  The first entries of a generated table are those of its seed table, so
+// the same checks serve both origins.
+int check_table_heads(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_inv, uint64_t f0, uint64_t f1, uint64_t b0,
+                      uint64_t b1)
+{
+    using u128 = unsigned __int128;
+    const uint64_t one = kind == NTTX_MONT64 ? (uint64_t)((((u128)1) << 64) % q) : 1;
+    const auto mul = [&](uint64_t a, uint64_t b) -> uint64_t {
+        if (kind == NTTX_MONT64)
+            return ntt::utils::MontgomeryTransformer<uint64_t>{k, 0, q}.mul(a, b);
+        return ntt::host::goldilocks_mul_reduce(a, b);
+    };
+    if (f0 != one || b0 != one)
+        return fail(NTTX_EINVAL, "entry 0 of a twiddle table is not the unit (2^64 mod q for NTTX_MONT64, 1 for NTTX_GOLDILOCKS)");
+    if (mul(f1, b1) != one)
+        return fail(NTTX_EINVAL, "entries 1 of the twiddle tables are not inverse to each other modulo q");
+    if (mul(f1, f1) != q - one)
+        return fail(NTTX_EINVAL, "entry 1 of the forward table is not a square root of -1 modulo q (psi is not a primitive 2n-th root)");
+    // n * n_inv = 1 in the table's form: n_inv * n (plain) = unit
+    uint64_t acc = n_inv; // n_inv * n by doubling (n is a power of two), canonical throughout
+    for (uint64_t m = n; m > 1; m >>= 1) {
+        const u128 d = (u128)acc * 2;
+        acc = (uint64_t)(d >= q ? d - q : d);
+    }
+    if (acc != one)
+        return fail(NTTX_EINVAL, "n_inv is not the inverse of n modulo q (in Montgomery form for NTTX_MONT64)");
+    return NTTX_OK;
+}
+
 // Plans from a root generate their tables on the devices from this size on (the host builds the
 // first DEVICE_TABLES_SEED entries and the per-level factors).  NTTX_HOST_TABLES=1: never.
 constexpr uint64_t DEVICE_TABLES_MIN_N = 1ull << 18;
@@ -1360,32 +1395,9 @@ int nttx_plan_create(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_in
     for (uint64_t i = 0; i < n; i++)
         if (psi_bo[i] >= q || psi_inv_bo[i] >= q)
             return fail(NTTX_EINVAL, "twiddle table entry is not a residue");
-    // Entry 0 of both tables is the unit in the table's form (ntt.rs:247-253: the chain starts from
-    // transform(1); ntt_goldilock.rs:200-206: from 1); entries 1 are psi^(n/2) and its inverse.  A
-    // table of another modulus, form or root pair fails these.
-    using u128 = unsigned __int128;
-    const uint64_t one = kind == NTTX_MONT64 ? (uint64_t)((((u128)1) << 64) % q) : 1;
-    const auto mul = [&](uint64_t a, uint64_t b) -> uint64_t {
-        if (kind == NTTX_MONT64)
-            return ntt::utils::MontgomeryTransformer<uint64_t>{k, 0, q}.mul(a, b);
-        return ntt::host::goldilocks_mul_reduce(a, b);
-    };
-    if (psi_bo[0] != one || psi_inv_bo[0] != one)
-        return fail(NTTX_EINVAL, "entry 0 of a twiddle table is not the unit (2^64 mod q for NTTX_MONT64, 1 for NTTX_GOLDILOCKS)");
-    if (mul(psi_bo[1], psi_inv_bo[1]) != one)
-        return fail(NTTX_EINVAL, "entries 1 of the twiddle tables are not inverse to each other modulo q");
-    if (mul(psi_bo[1], psi_bo[1]) != q - one)
-        return fail(NTTX_EINVAL, "entry 1 of the forward table is not a square root of -1 modulo q");
-    {
-        // n * n_inv = 1 in the table's form: n_inv * n (plain) = unit
-        uint64_t acc = n_inv; // n_inv * n by doubling (n is a power of two), canonical throughout
-        for (uint64_t m = n; m > 1; m >>= 1) {
-            const u128 d = (u128)acc * 2;
-            acc = (uint64_t)(d >= q ? d - q : d);
-        }
-        if (acc != one)
-            return fail(NTTX_EINVAL, "n_inv is not the inverse of n modulo q (in Montgomery form for NTTX_MONT64)");
-    }
+    rc = check_table_heads(kind, q, k, n, n_inv, psi_bo[0], psi_bo[1], psi_inv_bo[0], psi_inv_bo[1]);
+    if (rc != NTTX_OK)
+        return rc;
     TableSource src;
     src.h_fwd = psi_bo;
     src.h_inv = psi_inv_bo;
@@ -1459,6 +1471,8 @@ static int plan_from_root(int kind, uint64_t q, uint64_t psi, uint64_t n, const 
             src.step_fwd = steps(g);
             src.step_inv = steps(g_inv);
             int rc = check_plan_arguments(kind, q, k, n, n_inv);
+            if (rc == NTTX_OK)
+                rc = check_table_heads(kind, q, k, n, n_inv, src.seed_fwd[0], src.seed_fwd[1], src.seed_inv[0], src.seed_inv[1]);
             if (rc != NTTX_OK)
                 return rc;
             rc = create_plan(kind, q, k, n, n_inv, src, devices, n_devices, out);
@@ -1564,27 +1578,42 @@ int nttx_plan_tables(const nttx_plan* plan, uint64_t* psi_bo_out, uint64_t* psi_
     if (!plan)
         return fail(NTTX_EINVAL, "plan is NULL");
     if (plan->h_fwd.empty()) {
-        // tables were generated on the devices: the same values from the host builder
+        // The tables were generated on the devices: read the first device's copy back and undo the
+        // conversion to the kernels' format, so that the caller sees what the kernels multiply by.
         return guarded([&]() -> int {
-            try {
-                std::vector<uint64_t> f, b;
-                if (plan->kind == NTTX_MONT64) {
-                    auto t = ntt::host::build_montgomery_tables(plan->q, plan->psi, plan->n, plan->exact_k);
-                    f = std::move(t.powers_psi_bo);
-                    b = std::move(t.powers_psi_inv_bo);
-                } else {
-                    auto t = ntt::host::build_goldilocks_tables(plan->psi, plan->n, plan->exact_k);
-                    f = std::move(t.powers_psi_bo);
-                    b = std::move(t.powers_psi_inv_bo);
-                }
-                if (psi_bo_out)
-                    std::memcpy(psi_bo_out, f.data(), plan->n * sizeof(uint64_t));
-                if (psi_inv_bo_out)
-                    std::memcpy(psi_inv_bo_out, b.data(), plan->n * sizeof(uint64_t));
-            } catch (const ntt::Panic& p) {
-                return fail(NTTX_EINVAL, p.what());
+            int prev = 0;
+            (void)hipGetDevice(&prev);
+            HIP_TRY(hipSetDevice(plan->devices[0]));
+            const bool pairs = plan->policy == nttx_plan::SHOUP61 || plan->policy == nttx_plan::SHOUP61_NEAR;
+            const bool plain = plan->policy == nttx_plan::GOLDILOCKS_CANONICAL;
+            const ntt::utils::MontgomeryTransformer<uint64_t> mt =
+                plan->kind == NTTX_MONT64 ? (plan->exact_k ? ntt::utils::MontgomeryTransformer<uint64_t>::from_modulus_exact(plan->q)
+                                                           : ntt::utils::MontgomeryTransformer<uint64_t>::from_modulus(plan->q))
+                                          : ntt::utils::MontgomeryTransformer<uint64_t>{0, 0, plan->q};
+            int rc = NTTX_OK;
+            for (int dir = 0; dir < 2 && rc == NTTX_OK; dir++) {
+                uint64_t* out = dir == 0 ? psi_bo_out : psi_inv_bo_out;
+                const void* dev = dir == 0 ? plan->d_fwd[0] : plan->d_inv[0];
+                if (!out)
+                    continue;
+                auto copy = [&]() -> int {
+                    if (pairs) {
+                        std::vector<nttx::TwPair> tmp(plan->n);
+                        HIP_TRY(hipMemcpy(tmp.data(), dev, plan->n * sizeof(nttx::TwPair), hipMemcpyDeviceToHost));
+                        for (uint64_t i = 0; i < plan->n; i++)
+                            out[i] = mt.transform(tmp[i].w); // plain twiddle -> the reference's Montgomery form
+                    } else {
+                        HIP_TRY(hipMemcpy(out, dev, plan->n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                        if (plain)
+                            for (uint64_t i = 0; i < plan->n; i++)
+                                out[i] = mt.transform(out[i]);
+                    }
+                    return NTTX_OK;
+                };
+                rc = copy();
             }
-            return NTTX_OK;
+            (void)hipSetDevice(prev);
+            return rc;
         });
     }
     if (psi_bo_out)
@@ -1698,8 +1727,9 @@ namespace {
 constexpr size_t NOALLOC_MAX_BYTES = 32ull << 20;
 constexpr int NOALLOC_MAX_DEVICES = 64;
 static __device__ __attribute__((used)) __align__(256) uint64_t scratch[NOALLOC_MAX_BYTES / sizeof(uint64_t)];
-std::mutex scratch_lock;
+std::mutex scratch_lock;                            // guards scratch_ptr
 uint64_t* scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+std::mutex scratch_in_use[NOALLOC_MAX_DEVICES];     // held for a whole call: one user of a device's array at a time
 
 // Device address of this device's copy of `scratch`; `device` must be current.
 int scratch_on_current_device(int device, uint64_t** out)
@@ -1737,6 +1767,11 @@ int nttx_transform_host_noalloc(const nttx_plan* plan, uint64_t* data, size_t ba
                                  "(use nttx_forward_host / nttx_backward_host, which allocate)");
     const size_t bytes = (batch << plan->logn) * sizeof(uint64_t);
     const int device = plan->devices[0];
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES)
+        return fail(NTTX_ENODEV, "device index out of range for the static staging buffer");
+    // Every plan and thread of this process shares the device's one array: calls take turns (a static
+    // mutex per device: locking allocates nothing).
+    std::lock_guard<std::mutex> turn(scratch_in_use[device]);
     int prev = -1;
     HIP_TRY(hipGetDevice(&prev));
     if (prev != device)

@@ -17,7 +17,8 @@ device buffers over RCCL (backend "nccl"): with few rows per peer (the N = 2^28 
 two) as one group of point-to-point sends and receives, one message per row, each landing where
 the next phase reads it; with many rows per peer as one `all_to_all_single` of whole pieces
 followed by a reordering copy.  With another backend and GPU buffers (gloo, used by tests where
-several ranks share one GPU) the pieces are staged through host memory.
+several ranks share one GPU) both forms run on host copies of the buffers: the same messages, the
+same placement, only the transport differs.
 """
 import numpy as np
 
@@ -123,10 +124,8 @@ class ShardedTransform:
     MAX_ROWS_DIRECT = 16
 
     def _direct(self, x):
-        """Whether the grouped point-to-point exchange applies to buffer x."""
-        if self.world == 1 or self.rows_per_peer > self.MAX_ROWS_DIRECT:
-            return False
-        return self._device_collective or not x.is_cuda
+        """Whether the grouped point-to-point exchange applies."""
+        return self.world > 1 and self.rows_per_peer <= self.MAX_ROWS_DIRECT
 
     def _exchange_rows(self, dst, src, to_blocks):
         """The exchange without a reordering pass.  to_blocks: row c*R + rho of my column layout
@@ -136,6 +135,12 @@ class ShardedTransform:
         posted in the same (rho) order on both sides."""
         g, R, W = self.world, self.rows_per_peer, self.cols
         me = self.rank
+        if src.is_cuda and not self._device_collective:
+            # several ranks on one GPU (tests): the same messages between host copies of the buffers
+            h_dst = dst.cpu()
+            self._exchange_rows(h_dst, src.cpu(), to_blocks)
+            dst.copy_(h_dst)
+            return
         if to_blocks:
             s3, d3 = src.view(g, R, W), dst.view(R, g, W)
             send_of = lambda peer, rho: s3[peer, rho]

@@ -68,3 +68,25 @@ def test_every_header_function_is_bound_with_matching_types():
 def test_ctypes_binding_lists_the_same_symbols():
     from ntt_amd import _lib
     assert sorted(_lib.SYMBOLS) == sorted(header_functions())
+
+
+def test_shim_sources_call_only_methods_the_binding_has():
+    """rust/src/dft_gpu.rs (the bodies that replace the CPU loops) and rust/benches/ntt.rs are unbuilt
+    here; at least every `Plan` method and `ffi::` item they use must exist in rust/src/ffi.rs, and the
+    bench must name the crate as Cargo.toml does."""
+    ffi = open(os.path.join(ROOT, "rust", "src", "ffi.rs")).read()
+    plan_impl = ffi[ffi.index("impl Plan {"):]
+    plan_methods = set(re.findall(r"pub fn (\w+)\s*\(", plan_impl))
+    ffi_items = set(re.findall(r"pub (?:const|fn|struct) (\w+)", ffi))
+    shim = open(os.path.join(ROOT, "rust", "src", "dft_gpu.rs")).read()
+    shim = re.sub(r"//[^\n]*", "", shim)
+    used_methods = set(re.findall(r"\.expect\(\"[^\"]*\"\)\s*\.(\w+)\(", shim)) | set(re.findall(r"ffi::Plan::(\w+)\(", shim))
+    assert used_methods >= {"create", "forward", "backward", "forward_lazy", "backward_lazy"}
+    assert used_methods <= plan_methods, used_methods - plan_methods
+    used_items = set(re.findall(r"ffi::(\w+)", shim))
+    assert used_items <= ffi_items | {"Plan"}, used_items - ffi_items
+    # one forward and one backward core per table type, each ignoring LAZY
+    assert len(re.findall(r"pub fn forward_inplace_core<const LAZY: bool>", shim)) == 3
+    assert len(re.findall(r"pub fn backward_inplace_core<const LAZY: bool>", shim)) == 3
+    bench = open(os.path.join(ROOT, "rust", "benches", "ntt.rs")).read()
+    assert "use ntt::dft::ntt::Table;" in bench and "app::" not in re.sub(r"//[^\n]*", "", bench)

@@ -108,14 +108,16 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("world,kind,logn", [(2, "mont", 16), (4, "goldilocks", 20)])
+@pytest.mark.parametrize("world,kind,logn", [(2, "mont", 16), (4, "goldilocks", 20), (8, "goldilocks", 20), (8, "mont", 16)])
 def test_one_process_per_shard(tmp_path, world, kind, logn):
-    """ShardedTransform over torch.distributed; the ranks share GPU 0, so gloo carries the pieces."""
+    """ShardedTransform over torch.distributed; the ranks share GPU 0, so gloo carries the pieces.
+    Eight ranks at 2^20 have BASELINE configs[4]'s exchange shape (first pass of 4 stages, two rows per
+    peer, the grouped point-to-point form); eight at 2^16 have 32 rows per peer (the all-to-all form)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(HERE, "dist_gpu_worker.py"), kind, str(logn), str(tmp_path)]
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=170)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     for r in range(world):
         assert (tmp_path / ("ok%d" % r)).exists(), res.stdout[-2000:] + res.stderr[-2000:]
@@ -156,3 +158,51 @@ def test_two_to_the_28_goldilocks(amd):
     gpu.backward_inplace_distributed(split, 8)
     assert np.array_equal(split, x), "round trip"
     print("2^28: plan %.1fs, gpu %.1fs, oracle %.1fs, backward %.1fs" % (t1 - t0, t2 - t1, t3 - t2, time.time() - t3))
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="needs at least two GPUs")
+@pytest.mark.parametrize("peer_access", [True, False])
+def test_plan_over_all_devices(peer_access):
+    """On a multi-GPU host: one plan over every visible device; a host batch split over them
+    (nttx_*_host, one host thread per device), one transform split with one shard per device (peer
+    copies between distinct devices), with and without direct peer access (NTTX_NO_PEER_ACCESS is read
+    once per process, so each variant runs in a child)."""
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import _oracle as orc, ntt_amd
+nd = torch.cuda.device_count()
+shards = 1 << (nd.bit_length() - 1)
+devs = list(range(shards))
+QGL = 0xFFFFFFFF00000001
+n = 1 << 20
+psi = pow(7, (QGL - 1) // (2 * n), QGL)
+gpu, ref = ntt_amd.TableGoldilock.from_root(psi, n, devices=devs), orc.TableGoldilock.from_root(psi, n)
+x = orc.splitmix_residues(QGL, n, 77)
+want = x.copy(); ref.forward_inplace(want)
+a = x.copy(); gpu.forward_inplace_distributed(a, 0)
+assert np.array_equal(a, want), "split over devices"
+gpu.backward_inplace_distributed(a, 0)
+assert np.array_equal(a, x), "split round trip"
+Q61, R61 = 0x1FFFFFFFFFE00001, 0x0B4F9CB5C38B40B1
+n = 1 << 16
+t, r = ntt_amd.Table.from_prime_and_root(Q61, pow(R61, 16, Q61), n, devices=devs), orc.Table.new()
+batch = 8 * shards + 3
+b = orc.splitmix_residues(Q61, n * batch, 78)
+w = b.copy()
+for i in range(batch): r.forward_inplace(w[i * n:(i + 1) * n])
+t.forward_inplace_batch(b, batch)
+assert np.array_equal(b, w), "host batch over devices"
+print("ok", shards)
+""" % (os.path.dirname(HERE), HERE)
+    env = dict(os.environ)
+    if not peer_access:
+        env["NTTX_NO_PEER_ACCESS"] = "1"
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=170)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]

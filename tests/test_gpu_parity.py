@@ -334,6 +334,19 @@ def test_errors_match_reference_panics(amd):
         amd.TableAVX2.from_prime_and_root(Q61, psi61_for(4), 4)
 
 
+@pytest.mark.parametrize("logn", [10, 18, 20])
+def test_root_of_the_wrong_order_is_refused(amd, logn):
+    """A psi that is not a primitive 2n-th root makes a table whose entry 1 does not square to -1: refused
+    whether the tables are built on the host (n < 2^18) or generated on the device (from 2^18 on)."""
+    n = 1 << logn
+    for bad in (psi61_for(n // 2), psi61_for(n) * psi61_for(n) % Q61, 1):
+        with pytest.raises(amd.Panic, match="square root of -1|inverse"):
+            amd.Table.from_prime_and_root(Q61, bad, n)
+    with pytest.raises(amd.Panic, match="square root of -1|inverse"):
+        amd.TableGoldilock.from_root(psigl_for(n // 2), n)
+    amd.Table.from_prime_and_root(Q61, psi61_for(n), n)  # the right root is taken
+
+
 def test_device_resident_batch(amd):
     """nttx_forward_device / nttx_backward_device on a torch tensor, checked on sampled transforms."""
     import torch

@@ -1,0 +1,158 @@
+// Memory-only models of the 8-stage pass kernels' tile shapes on gfx950: every kernel reads each
+// element of a 2 GiB batch (4096 x 2^16 u64) once and writes it once, in place, with the access shapes
+// and cache policy (nt) of the real passes and no arithmetic -- what the memory system gives each
+// shape.  One workgroup of 256 threads per tile of 4096 elements, 16 elements per thread.
+//
+//   strided   256 rows x 16 columns of one transform, rows 256 elements apart (first forward pass)
+//   xb        the same 256-element block of 16 consecutive transforms: 16 runs of 2 KiB, 512 KiB apart
+//             (cross-batch tile of the pass with the last eight stages)
+// Access forms of a side (load or store):
+//   A8    8 bytes per lane, a wave instruction = four 128-byte segments in four rows / runs
+//   C16   16 bytes per lane, a wave instruction = 1 KiB contiguous
+//   C8    8 bytes per lane, a wave instruction = 512 bytes contiguous
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int NT = 2;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(uint64_t* p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, 0xffffffff, 0x00020000);
+}
+
+enum Form { A8, C16, C8 };
+
+// element offsets (from the tile's first element) of access i of a thread, for a tile made of 16
+// runs of 256 elements `run_stride` apart (xb), in the given form
+template <int FORM>
+__device__ __forceinline__ uint32_t xb_offset(int i, uint32_t t, uint32_t run_stride)
+{
+    if (FORM == A8) { // thread (sigma = t >> 4, rlow = t & 15), element rlow + 16 i of run sigma
+        return (t >> 4) * run_stride + (t & 15) + 16u * i;
+    } else if (FORM == C16) { // wave w owns runs 4w..4w+3; access i (0..7): half i & 1 of run 4w + (i >> 1)
+        const uint32_t w = t >> 6, lane = t & 63;
+        return (4 * w + (i >> 1)) * run_stride + (i & 1) * 128u + 2 * lane;
+    } else { // C8: access i (0..15): quarter i & 3 of run 4w + (i >> 2)
+        const uint32_t w = t >> 6, lane = t & 63;
+        return (4 * w + (i >> 2)) * run_stride + (i & 3) * 64u + lane;
+    }
+}
+
+template <int LOAD, int STORE, int LAUX = NT, int SAUX = NT>
+__global__ __launch_bounds__(256) void xb_kernel(uint64_t* d, uint32_t s0 /* log2 blocks per transform */)
+{
+    const uint64_t tile = blockIdx.x;
+    const uint32_t run_stride = 1u << (s0 + 8);
+    uint64_t* base = d + ((((tile >> s0) << 4) << s0) + (tile & ((1ull << s0) - 1))) * 256;
+    const __amdgpu_buffer_rsrc_t r = rsrc(base);
+    const uint32_t t = threadIdx.x;
+    uint64_t v[16];
+    if (LOAD == C16) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(r, xb_offset<C16>(i, t, run_stride) * 8, 0, LAUX);
+            v[2 * i] = ((uint64_t)x.y << 32) | x.x;
+            v[2 * i + 1] = ((uint64_t)x.w << 32) | x.z;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const u32x2_t x = __builtin_amdgcn_raw_buffer_load_b64(r, xb_offset<LOAD>(i, t, run_stride) * 8, 0, LAUX);
+            v[i] = ((uint64_t)x.y << 32) | x.x;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        v[i] += 1;
+    __syncthreads(); // the real kernels exchange through LDS here: every load has landed before any store
+    if (STORE == C16) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const u32x4_t x = {(uint32_t)v[2 * i], (uint32_t)(v[2 * i] >> 32), (uint32_t)v[2 * i + 1], (uint32_t)(v[2 * i + 1] >> 32)};
+            __builtin_amdgcn_raw_buffer_store_b128(x, r, xb_offset<C16>(i, t, run_stride) * 8, 0, SAUX);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const u32x2_t x = {(uint32_t)v[i], (uint32_t)(v[i] >> 32)};
+            __builtin_amdgcn_raw_buffer_store_b64(x, r, xb_offset<STORE>(i, t, run_stride) * 8, 0, SAUX);
+        }
+    }
+}
+
+// strided tile, both sides A8 (as the first forward / last backward pass); G > 0: XCD-grouped order
+__global__ __launch_bounds__(256) void strided_kernel(uint64_t* d, uint32_t G)
+{
+    uint64_t tile = blockIdx.x;
+    if (G)
+        tile = ((uint64_t)(blockIdx.x / (8 * G)) * 8 + blockIdx.x % 8) * G + (blockIdx.x / 8) % G;
+    uint64_t* base = d + (tile >> 4) * 65536 + (tile & 15) * 16;
+    const __amdgpu_buffer_rsrc_t r = rsrc(base);
+    const uint32_t t = threadIdx.x;
+    const uint32_t lane = ((t >> 4) * 256 + (t & 15)) * 8; // row t >> 4, column t & 15
+    uint64_t v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const u32x2_t x = __builtin_amdgcn_raw_buffer_load_b64(r, lane, i * 16 * 256 * 8, NT);
+        v[i] = ((uint64_t)x.y << 32) | x.x;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        v[i] += 1;
+    __syncthreads();
+    // second round's layout: rows 16 (t >> 4) + i
+    const uint32_t lane2 = ((t >> 4) * 16 * 256 + (t & 15)) * 8;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const u32x2_t x = {(uint32_t)v[i], (uint32_t)(v[i] >> 32)};
+        __builtin_amdgcn_raw_buffer_store_b64(x, r, lane2, i * 256 * 8, NT);
+    }
+}
+
+template <class F> void timeit(const char* name, F launch, double bytes)
+{
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int r = 0; r < 3; r++) launch();
+    CHECK(hipDeviceSynchronize());
+    float best = 1e9, sum = 0;
+    const int reps = 10;
+    for (int r = 0; r < reps; r++) {
+        CHECK(hipEventRecord(e0)); launch(); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best; sum += ms;
+    }
+    printf("%-44s best %.3f ms  avg %.3f ms  -> %.2f TB/s (read+write)\n", name, best, sum / reps, bytes / (sum / reps * 1e-3) / 1e12);
+}
+
+int main()
+{
+    const size_t n = (size_t)4096 * 65536;
+    uint64_t* d;
+    CHECK(hipMalloc(&d, n * 8));
+    CHECK(hipMemset(d, 1, n * 8));
+    const double bytes = 2.0 * n * 8;
+    const unsigned grid = (unsigned)(n / 4096);
+    for (int round = 0; round < 2; round++) {
+        timeit("strided A8 -> A8, plain order", [&] { strided_kernel<<<grid, 256>>>(d, 0); }, bytes);
+        timeit("strided A8 -> A8, XCD groups of 16", [&] { strided_kernel<<<grid, 256>>>(d, 16); }, bytes);
+        timeit("xb A8 -> C16 (fwd contig as shipped)", [&] { xb_kernel<A8, C16><<<grid, 256>>>(d, 8); }, bytes);
+        timeit("xb A8 -> C8", [&] { xb_kernel<A8, C8><<<grid, 256>>>(d, 8); }, bytes);
+        timeit("xb A8 -> A8", [&] { xb_kernel<A8, A8><<<grid, 256>>>(d, 8); }, bytes);
+        timeit("xb C16 -> A8 (bwd contig as shipped)", [&] { xb_kernel<C16, A8><<<grid, 256>>>(d, 8); }, bytes);
+        timeit("xb C16 (default policy) -> A8 (nt)", [&] { xb_kernel<C16, A8, 0, NT><<<grid, 256>>>(d, 8); }, bytes);
+        timeit("xb C16 (default) -> A8 (default)", [&] { xb_kernel<C16, A8, 0, 0><<<grid, 256>>>(d, 8); }, bytes);
+        timeit("xb C8 (default) -> A8 (default)", [&] { xb_kernel<C8, A8, 0, 0><<<grid, 256>>>(d, 8); }, bytes);
+        timeit("xb A8 (default) -> C16 (default)", [&] { xb_kernel<A8, C16, 0, 0><<<grid, 256>>>(d, 8); }, bytes);
+        timeit("xb C8 -> A8", [&] { xb_kernel<C8, A8><<<grid, 256>>>(d, 8); }, bytes);
+        timeit("xb C16 -> C16", [&] { xb_kernel<C16, C16><<<grid, 256>>>(d, 8); }, bytes);
+        timeit("xb C8 -> C8", [&] { xb_kernel<C8, C8><<<grid, 256>>>(d, 8); }, bytes);
+        // plain contiguous tiles (s0 = 0 makes the 16 runs adjacent: one 32 KiB run)
+        timeit("contiguous 32 KiB tile C16 -> C16", [&] { xb_kernel<C16, C16><<<grid, 256>>>(d, 0); }, bytes);
+        timeit("contiguous 32 KiB tile C8 -> C8", [&] { xb_kernel<C8, C8><<<grid, 256>>>(d, 0); }, bytes);
+    }
+    return 0;
+}
