@@ -102,6 +102,17 @@ int nttx_plan_tables(const nttx_plan *plan, uint64_t *psi_bo_out, uint64_t *psi_
  * "goldilocks_canonical" (NTTX_MONT64 with q = 0xffffffff00000001, Table::new_goldilock,
  * ntt.rs:60-62), "goldilocks" (NTTX_GOLDILOCKS).  Static string; "" for a NULL plan. */
 const char *nttx_plan_policy(const nttx_plan *plan);
+/*
+ * Whether a plan's kernels take one of the shortcuts that depend on its constants (1 / 0; -1 for an
+ * unknown name or a NULL plan).  No counterpart in the reference; tests use it to assert that the
+ * path they mean to check is the one that runs.
+ *   "pow2_twiddles"  NTTX_GOLDILOCKS arithmetic: the twiddles of the first four forward / last four
+ *                    inverse stages are applied as shifts (entries 1..15 of both tables are the powers
+ *                    of two of a table with psi^(n/32) = 2^39, e.g. psi = 7^((q-1)/2n))
+ *   "shift_scaling"  q < 2^61: the n^-1 factor of the inverse transform's sums (ntt.rs:231-235) is applied
+ *                    as an exact division by n = 2^k instead of a product (n^-1 = 2^-k mod q, 8 <= k <= 24)
+ */
+int nttx_plan_feature(const nttx_plan *plan, const char *name);
 
 /*
  * In-place transforms of `batch` independent length-n vectors stored back to back in HOST

@@ -35,6 +35,7 @@ SYMBOLS = {
     "nttx_pass_count": (C.c_int, [_vp]),
     "nttx_pass_describe": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, _sz]),
     "nttx_run_pass_device": (C.c_int, [_vp, C.c_int, _vp, _sz, C.c_int, C.c_int, _vp]),
+    "nttx_plan_feature": (C.c_int, [_vp, C.c_char_p]),
     "nttx_clock_probe_device": (C.c_int, [C.c_int, _vp, C.c_int, _vp]),
     "nttx_forward_distributed": (C.c_int, [_vp, _vp, C.c_int]),
     "nttx_backward_distributed": (C.c_int, [_vp, _vp, C.c_int]),

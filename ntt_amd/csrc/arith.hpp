@@ -243,6 +243,7 @@ struct Shoup61T {
     using TwElem = TwPair;
     static constexpr bool CONDITIONS_INPUT = true;
     static constexpr bool DEFERRED_CHECK = false;
+    static constexpr bool HAS_POW2_TWIDDLES = false;
     static NTTX_HD uint64_t modulus(const Ctx& c) { return c.q; }
     // Inputs below this bound need no conditioning: both butterflies take values in [0, 4q), so
     // the lazily reduced inputs the reference documents for its *_lazy methods ([0, 2q),
@@ -520,6 +521,7 @@ struct Mont {
     using TwElem = uint64_t;
     static constexpr bool CONDITIONS_INPUT = true;
     static constexpr bool DEFERRED_CHECK = false;
+    static constexpr bool HAS_POW2_TWIDDLES = false;
     static NTTX_HD uint64_t modulus(const Ctx& c) { return c.q; }
     static NTTX_HD uint64_t input_bound(const Ctx& c) { return c.q; } // strict residues only
     struct Tw {
@@ -617,6 +619,7 @@ struct Goldilocks {
     using Ctx = GoldilocksCtx;
     using TwElem = uint64_t;
     static constexpr bool CONDITIONS_INPUT = false; // TableGoldilock has no input sweep
+    static constexpr bool HAS_POW2_TWIDDLES = true;
     static NTTX_HD uint64_t modulus(const Ctx&) { return 0xffffffff00000001ull; }
     static NTTX_HD uint64_t input_bound(const Ctx&) { return 0xffffffff00000001ull; }
     struct Tw {
@@ -733,6 +736,18 @@ struct Goldilocks {
 #endif
     }
 
+    // m * (2^32 - 1)
+    static NTTX_HD uint64_t mul_eps(uint32_t m)
+    {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+        uint64_t d, unused;
+        asm("v_mad_u64_u32 %0, %1, %2, -1, 0" : "=v"(d), "=s"(unused) : "v"(m));
+        return d;
+#else
+        return (uint64_t)m * EPS;
+#endif
+    }
+
     // Canonical a*b mod q unless the returned word `top` (the result's high half) is 0xffffffff.
     //
     // With the 128-bit product as 32-bit limbs x0..x3: a*b = lo + 2^64*x2 + 2^96*x3 with
@@ -764,6 +779,13 @@ struct Goldilocks {
             x3 = hi32(hh);
         }
 #endif
+        return reduce_limbs_fast(lo, x2, x3, top);
+    }
+
+    // lo + 2^64 x2 + 2^96 x3 (32-bit x2, x3) modulo q, by the argument above: canonical unless the
+    // returned word `top` (the result's high half) is 0xffffffff.
+    static NTTX_HD uint64_t reduce_limbs_fast(uint64_t lo, uint32_t x2, uint32_t x3, uint32_t& top)
+    {
         Carry c;
         const uint64_t x = mad_eps(x2, lo, c);
         uint32_t tl, th;
@@ -785,6 +807,108 @@ struct Goldilocks {
 #endif
         top = th;
         return pack64(tl, th);
+    }
+    // the same with x3 = 0
+    static NTTX_HD uint64_t reduce_limbs_fast(uint64_t lo, uint32_t x2, uint32_t& top)
+    {
+        Carry c;
+        const uint64_t x = mad_eps(x2, lo, c);
+        uint32_t tl, th;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NTTX_NO_ASM_MAD)
+        asm("s_nop 1\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %3, %4\n\t"    // th = xh + c
+            "v_subbrev_co_u32 %0, vcc, 0, %2, %4\n\t" // tl = xl - c, vcc = borrow
+            "s_nop 1\n\t"
+            "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"      // th -= borrow
+            : "=&v"(tl), "=&v"(th)
+            : "v"(lo32(x)), "v"(hi32(x)), "s"(c)
+            : "vcc");
+#else
+        {
+            const uint64_t t = x - c + ((uint64_t)c << 32);
+            tl = lo32(t);
+            th = hi32(t);
+        }
+#endif
+        top = th;
+        return pack64(tl, th);
+    }
+
+    // ---- twiddles that are powers of two -------------------------------------------------------
+    // 2 has order 192 modulo q (2^96 = -1), so every root of unity of order up to 64 is +-2^k: the
+    // twiddles of the first five forward stages (and the last five inverse ones) of ANY transform.
+    // For a table whose psi^(n/32) is 2^39 (= 7^((q-1)/64): the reference's own psi,
+    // ntt_goldilock.rs:51, and every psi = 7^((q-1)/2n)) entry x < 32 of the forward table is
+    // 2^pow2_exponent(x) and that of the inverse table 2^(192 - pow2_exponent(x)).
+    static constexpr int pow2_exponent(int x, bool inverse)
+    {
+        int u = 0;
+        for (int t = x; t; t >>= 1)
+            u++; // x has u bits: stage u
+        int rev = 0;
+        for (int i = 0; i < u; i++)
+            rev |= ((x >> i) & 1) << (u - 1 - i);
+        const int e = (39 * rev * (1 << (5 - u))) % 192;
+        return inverse ? (192 - e) % 192 : e;
+    }
+    static constexpr uint64_t POW2_ROOT64 = 0x8000000000ull; // 2^39, the psi^(n/32) of such tables
+
+    // a * 2^K mod q for 0 < K < 96, K not a multiple of 32: the 96-bit a << (K mod 32) as limbs
+    // y0, y1, y2, placed K / 32 limbs up.  Canonical unless `top` (the result's high half) is 0xffffffff;
+    // three shifts and four or five more instructions against the thirteen of mul_fast.
+    template <int K>
+    static NTTX_HD uint64_t mul_pow2_fast(uint64_t a, uint32_t& top)
+    {
+        static_assert(K > 0 && K < 96 && K % 32 != 0, "shift by a whole limb is not needed by any twiddle");
+        constexpr int S = K % 32, J = K / 32;
+        const uint32_t a0 = lo32(a), a1 = hi32(a);
+        const uint32_t y0 = a0 << S, y1 = (a1 << S) | (a0 >> (32 - S)), y2 = a1 >> (32 - S);
+        if (J == 0)
+            return reduce_limbs_fast(pack64(y0, y1), y2, top);        // y0 + 2^32 y1 + 2^64 y2
+        if (J == 1)
+            return reduce_limbs_fast(pack64(0, y0), y1, y2, top);     // 2^32 y0 + 2^64 y1 + 2^96 y2
+        // 2^64 y0 + 2^96 y1 + 2^128 y2 = y0 (2^32 - 1) - (y1 + 2^32 y2): both canonical (y2 < 2^31), so
+        // the borrow-corrected difference is the canonical product exactly
+        return sub_fast(mul_eps(y0), pack64(y1, y2), top);
+    }
+
+    // Butterflies whose twiddle is 2^E, E in [0, 192) known at compile time; 2^E = -2^(E - 96) for
+    // E >= 96.  Same contract as ct_fast / gs_fast: outputs equal the strict butterfly with the
+    // twiddle's canonical value unless one of the watched words is 0xffffffff.
+    //
+    // Negative twiddle, forward (v = q - v' for v' = b 2^(E-96) != 0): add_strict(u, q - v') equals
+    // u - v' (+ q on borrow) except when u = v' (the reference leaves q where this form gives 0), and
+    // for v' = 0 except when u > q; sub_ct_strict(u, q - v') equals u + v' (- q on carry) except when that
+    // lies in [q, 2^64).  So the roles of add_fast and sub_fast swap, and the one new case -- a zero
+    // difference -- is watched through its high word minus one.
+    static constexpr int TOPS_CT_POW2 = 4;
+    template <int E>
+    static NTTX_HD void ct_pow2_fast(uint64_t& a, uint64_t& b, uint32_t* tops)
+    {
+        const uint64_t u = a;
+        const uint64_t v = mul_pow2_fast<E % 96>(b, tops[0]);
+        if (E < 96) {
+            a = add_fast(u, v, tops[1]);
+            b = sub_fast(u, v, tops[2]);
+            tops[3] = 0;
+        } else {
+            a = sub_fast(u, v, tops[1]);
+            b = add_fast(u, v, tops[2]);
+            tops[3] = tops[1] - 1; // 0xffffffff when the difference may be zero
+        }
+    }
+    // Backward form.  Operands must lie in [0, q] -- true of every stage but the first of an inverse
+    // transform, since add_strict and mul_reduce leave nothing larger: only then is the borrow-corrected
+    // v - u the negative of the reference's u - v modulo q (for larger operands the reference's own
+    // difference wraps modulo 2^64 and would have to be reproduced as it is).
+    template <int E>
+    static NTTX_HD void gs_pow2_fast(uint64_t& a, uint64_t& b, uint32_t* tops)
+    {
+        const uint64_t u = a, v = b;
+        uint32_t unused;
+        a = add_fast(u, v, tops[0]);
+        // mul_reduce is canonical for any operand, and (u - v) * -2^k = (v - u) * 2^k
+        b = mul_pow2_fast<E % 96>(E < 96 ? sub_fast(u, v, unused) : sub_fast(v, u, unused), tops[1]);
     }
 
     // u + v mod 2^64, minus q if that carried.  Differs from add_strict only when the sum did not

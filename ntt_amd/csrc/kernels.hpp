@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "arith.hpp"
 
 namespace nttx {
@@ -54,6 +56,8 @@ enum : uint32_t {
     PASS_POINTWISE = 256u,     // first pass of a backward transform: multiply by the vector at data2 first
     PASS_OFFSET32 = 512u,      // every element of a tile lies within 2^31 bytes of the tile's first: buffer addressing
     PASS_LAZY = 1024u,         // outputs of the transform in the policy's lazy range ([0, 2q)) instead of canonical
+    PASS_POW2_TWIDDLES = 4096u, // host side only: STRIDED 8-stage pass with s0 = 0 on a table whose entries 1..15 are the
+                               // standard powers of two -- selects the kernel whose first radix-16 round multiplies by shifts
     PASS_DEBUG_HOT_TILES = 2048u // profiling aid (NTTX_DEBUG_HOT_TILES=1): every workgroup works on one of the first 64
                                // tiles, so all traffic is served by the L2s -- the pass time with HBM out of the picture
 };
@@ -242,6 +246,99 @@ __device__ __forceinline__ void radix(uint64_t (&x)[1 << K], const Src& w, const
                 A::gs(x[i], x[i + half], s, c);
         }
     }
+}
+
+// Compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// radix<A, 4, FWD> for a policy with DEFERRED_CHECK whose 15 twiddles are the table's entries 1..15 and
+// known powers of two (A::pow2_exponent): the stages 1..4 of a forward transform, or 4..1 of an inverse
+// one, on a table with the standard psi^(n/32).  The products become shifts (A::ct_pow2_fast /
+// gs_pow2_fast); the strict redo of a suspect stage and the inverse stage that carries the n^-1 factor
+// take the twiddle values from `w` as radix() does.
+template <class A, bool FWD, class Src>
+__device__ __forceinline__ void radix16_pow2(uint64_t (&x)[16], const Src& w, const typename A::Ctx& c, int scale)
+{
+    constexpr int K = 4, M = 16;
+    uint64_t in[M];
+    static_for<0, K>([&](auto step_c) {
+        constexpr int step = decltype(step_c)::value + 1;
+        constexpr int u = FWD ? step : K + 1 - step;
+        constexpr int half = M >> u;
+        const bool last = !FWD && u == 1 && scale;
+#pragma unroll
+        for (int i = 0; i < M; i++)
+            in[i] = x[i];
+        uint32_t suspect = 0, held = 0;
+        bool holding = false;
+        auto watch = [&](const uint32_t* tops, int count) {
+#pragma unroll
+            for (int k = 0; k < count; k++) {
+                if (holding) {
+                    suspect = A::max3(suspect, held, tops[k]);
+                    holding = false;
+                } else {
+                    held = tops[k];
+                    holding = true;
+                }
+            }
+        };
+        if (last) {
+            const typename A::Tw s = A::scaled(w.get(1), c);
+#pragma unroll
+            for (int i = 0; i < half; i++) {
+                uint32_t tops[3];
+                A::gs_last_fast(x[i], x[i + half], s, c, tops);
+                watch(tops, A::TOPS_GS_LAST);
+            }
+        } else {
+            static_for<0, (1 << (u - 1))>([&](auto b_c) {
+                constexpr int b = decltype(b_c)::value;
+                constexpr int E = A::pow2_exponent((1 << (u - 1)) + b, !FWD);
+#pragma unroll
+                for (int i = 0; i < half; i++) {
+                    const int lo = b * 2 * half + i;
+                    uint32_t tops[4];
+                    if (FWD) {
+                        A::template ct_pow2_fast<E>(x[lo], x[lo + half], tops);
+                        watch(tops, E < 96 ? 3 : A::TOPS_CT_POW2);
+                    } else {
+                        A::template gs_pow2_fast<E>(x[lo], x[lo + half], tops);
+                        watch(tops, A::TOPS_GS);
+                    }
+                }
+            });
+        }
+        if (holding)
+            suspect = A::max3(suspect, held, 0);
+        if (__builtin_expect(suspect == A::SUSPECT, 0)) {
+#pragma unroll
+            for (int b = 0; b < (1 << (u - 1)); b++) {
+                typename A::Tw s = w.get((1 << (u - 1)) + b);
+                if (last)
+                    s = A::scaled(s, c);
+#pragma unroll
+                for (int i = 0; i < half; i++) {
+                    const int lo = b * 2 * half + i;
+                    x[lo] = in[lo];
+                    x[lo + half] = in[lo + half];
+                    if (FWD)
+                        A::ct_strict(x[lo], x[lo + half], s, c);
+                    else if (last)
+                        A::gs_last_strict(x[lo], x[lo + half], s, c);
+                    else
+                        A::gs_strict(x[lo], x[lo + half], s, c);
+                }
+            }
+        }
+    });
 }
 
 // The reference's first sweep accepts any u64 (ntt.rs:125-127).  Values the butterflies can take
@@ -976,7 +1073,9 @@ __device__ __forceinline__ void move_runs(uint64_t (&x)[16], const PassParams& p
     }
 }
 
-template <class A, bool FWD, bool CONTIG>
+// POW2: the round with the larger strides multiplies by shifts (radix16_pow2); the host launches that
+// instantiation for passes with s0 = 0 of plans whose table entries 1..15 are the standard powers of two.
+template <class A, bool FWD, bool CONTIG, bool POW2 = false>
 __device__ __forceinline__ void pass_8h(const PassParams& p, const TileGeom<8, CONTIG>& g, const typename A::Ctx& c,
                                         uint32_t* plane, typename A::TwElem* ldstw)
 {
@@ -1017,8 +1116,12 @@ __device__ __forceinline__ void pass_8h(const PassParams& p, const TileGeom<8, C
         ra.load_global(x, p, g, c);
         stage_twiddles();
         __syncthreads();
-        if (math_a)
-            radix<A, 4, true>(x, set_a, c, SCALE_NONE);
+        if (math_a) {
+            if constexpr (POW2)
+                radix16_pow2<A, true>(x, set_a, c, SCALE_NONE);
+            else
+                radix<A, 4, true>(x, set_a, c, SCALE_NONE);
+        }
         exchange_planes(x, ra, rb, plane);
         if (math_b)
             radix<A, 4, true>(x, set_b, c, SCALE_NONE);
@@ -1040,8 +1143,12 @@ __device__ __forceinline__ void pass_8h(const PassParams& p, const TileGeom<8, C
         if (math_b)
             radix<A, 4, false>(x, set_b, c, SCALE_NONE);
         exchange_planes(x, rb, ra, plane);
-        if (math_a)
-            radix<A, 4, false>(x, set_a, c, scale);
+        if (math_a) {
+            if constexpr (POW2)
+                radix16_pow2<A, false>(x, set_a, c, scale);
+            else
+                radix<A, 4, false>(x, set_a, c, scale);
+        }
         ra.store_global(x, p, g);
     }
 }
@@ -1064,9 +1171,11 @@ constexpr int pass_waves()
     return half_lds_shape<CONTIG, K1, K2, XB>() ? NTTX_HALF_WAVES : 4;
 }
 
-template <class A, bool FWD, bool CONTIG, int K1, int K2, bool XB = false>
+template <class A, bool FWD, bool CONTIG, int K1, int K2, bool XB = false, bool POW2 = false>
 __global__ __launch_bounds__(THREADS, (pass_waves<CONTIG, K1, K2, XB>())) void pass_kernel(PassParams p, typename A::Ctx c)
 {
+    static_assert(!POW2 || (A::HAS_POW2_TWIDDLES && half_lds_shape<CONTIG, K1, K2, XB>() && !CONTIG),
+                  "shift twiddles: the STRIDED 8-stage pass of a policy that has them");
     constexpr int K = K1 + K2;
     // Workgroups are handed to the 8 XCDs round-robin (id % 8).  With xcd_group = G the tiles are
     // dealt so that each XCD works on runs of G consecutive tiles: workgroup id -> run
@@ -1084,7 +1193,7 @@ __global__ __launch_bounds__(THREADS, (pass_waves<CONTIG, K1, K2, XB>())) void p
     if constexpr (half_lds_shape<CONTIG, K1, K2, XB>()) {
         __shared__ __attribute__((aligned(16))) uint32_t plane[LDS_ELEMS];
         __shared__ __attribute__((aligned(16))) typename A::TwElem ldstw[LDSTW_ELEMS];
-        pass_8h<A, FWD, CONTIG>(p, g, c, plane, ldstw);
+        pass_8h<A, FWD, CONTIG, POW2>(p, g, c, plane, ldstw);
     } else if constexpr (K1 == 4 && K2 == 4) {
         __shared__ __attribute__((aligned(16))) uint64_t lds[LDS_ELEMS];
         __shared__ __attribute__((aligned(16))) typename A::TwElem ldstw[LDSTW_ELEMS];

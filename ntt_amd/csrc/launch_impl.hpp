@@ -6,7 +6,7 @@
 
 namespace nttx {
 
-template <class A, bool FWD, bool CONTIG, int K1, int K2, bool XB = false>
+template <class A, bool FWD, bool CONTIG, int K1, int K2, bool XB = false, bool POW2 = false>
 hipError_t launch_one(const PassParams& p, const typename A::Ctx& c, unsigned grid, hipStream_t s)
 {
     (void)hipGetLastError(); // drop any error an earlier, unrelated call left behind on this thread
@@ -19,7 +19,7 @@ hipError_t launch_one(const PassParams& p, const typename A::Ctx& c, unsigned gr
 #else
     constexpr unsigned extra_lds = 0;
 #endif
-    hipLaunchKernelGGL((pass_kernel<A, FWD, CONTIG, K1, K2, XB>), dim3(grid), dim3(THREADS), extra_lds, s, p, c);
+    hipLaunchKernelGGL((pass_kernel<A, FWD, CONTIG, K1, K2, XB, POW2>), dim3(grid), dim3(THREADS), extra_lds, s, p, c);
     return hipGetLastError();
 }
 
@@ -27,6 +27,10 @@ template <class A, bool FWD>
 hipError_t launch_shape(const PassDesc& d, const PassParams& p, const typename A::Ctx& c, unsigned grid, hipStream_t s)
 {
     const int key = ((p.flags & PASS_CROSS_BATCH) ? 1000 : 0) + (d.contig ? 100 : 0) + d.k1 * 10 + d.k2;
+    if constexpr (A::HAS_POW2_TWIDDLES && half_lds_shape<false, 4, 4, false>()) {
+        if (key == 44 && (p.flags & PASS_POW2_TWIDDLES)) // the first four stages' twiddles as shifts
+            return launch_one<A, FWD, false, 4, 4, false, true>(p, c, grid, s);
+    }
     switch (key) {
     case 1144: return launch_one<A, FWD, true, 4, 4, true>(p, c, grid, s);
     // odd stage counts: plans of the corrected constructor with odd log2 n

@@ -167,6 +167,7 @@ struct nttx_plan {
     // generated its tables on the devices (from_root with n >= DEVICE_TABLES_MIN_N): nttx_plan_tables
     // then rebuilds them on the host from (q, psi, n).
     std::vector<uint64_t> h_fwd, h_inv;
+    bool pow2_twiddles = false; // Goldilocks kernels: entries 1..15 of both tables are the standard powers of two
     uint64_t psi = 0;     // root the plan was created from (generated tables only)
     bool exact_k = false; // created by nttx_plan_create_from_root_exact_k
     std::vector<int> devices;
@@ -369,6 +370,8 @@ int launch_pass(const nttx_plan* plan, int slot, const PassDesc& d, PassParams p
         group = 1ull << (p.logB - TILE_LOG);
     if (group > 0 && group <= (1u << 20) && tiles % (8 * group) == 0)
         p.xcd_group = (uint32_t)group;
+    if (plan->pow2_twiddles && p.s0 == 0 && !d.contig && d.k1 == 4 && d.k2 == 4)
+        p.flags |= PASS_POW2_TWIDDLES; // this pass's first four stages read table entries 1..15
     apply_debug_flags(p);
     hipError_t e;
     switch (plan->policy) {
@@ -1298,6 +1301,22 @@ int create_plan(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_inv, co
         const ntt::utils::MontgomeryTransformer<uint64_t> mt{k, 0, q};
         plan->gctx = nttx::GoldilocksCtx{mt.reduce((u128)n_inv)};
     }
+    if ((plan->policy == nttx_plan::GOLDILOCKS || plan->policy == nttx_plan::GOLDILOCKS_CANONICAL) && n >= 16 &&
+        std::getenv("NTTX_NO_POW2_TWIDDLES") == nullptr) {
+        // Twiddles of the first four stages as shifts: taken when entries 1..15 of both tables are exactly
+        // the powers of two the kernels have compiled in (tables of every psi with psi^(n/32) = 2^39).
+        const ntt::utils::MontgomeryTransformer<uint64_t> mt{k, 0, q};
+        const uint64_t* f = src.seed ? src.seed_fwd.data() : src.h_fwd;
+        const uint64_t* b = src.seed ? src.seed_inv.data() : src.h_inv;
+        bool match = true;
+        for (int x = 1; x < 16 && match; x++) {
+            const uint64_t fx = kind == NTTX_MONT64 ? mt.reduce((u128)f[x]) : f[x];
+            const uint64_t bx = kind == NTTX_MONT64 ? mt.reduce((u128)b[x]) : b[x];
+            match = fx == ntt::utils::mod_exp_u64(2, (uint64_t)nttx::Goldilocks::pow2_exponent(x, false), q) &&
+                    bx == ntt::utils::mod_exp_u64(2, (uint64_t)nttx::Goldilocks::pow2_exponent(x, true), q);
+        }
+        plan->pow2_twiddles = match;
+    }
     int rc = guarded([&] {
         if (src.seed == 0) {
             plan->h_fwd.assign(src.h_fwd, src.h_fwd + n);
@@ -1671,6 +1690,17 @@ const char* nttx_plan_policy(const nttx_plan* plan)
     case nttx_plan::GOLDILOCKS_CANONICAL: return "goldilocks_canonical";
     }
     return "";
+}
+
+int nttx_plan_feature(const nttx_plan* plan, const char* name)
+{
+    if (!plan || !name)
+        return -1;
+    if (std::strcmp(name, "pow2_twiddles") == 0)
+        return plan->pow2_twiddles ? 1 : 0;
+    if (std::strcmp(name, "shift_scaling") == 0)
+        return (plan->policy == nttx_plan::SHOUP61 || plan->policy == nttx_plan::SHOUP61_NEAR) && plan->sctx.scale_shift != 0 ? 1 : 0;
+    return -1;
 }
 
 int nttx_negacyclic_mul_host(const nttx_plan* plan, uint64_t* a, const uint64_t* b, size_t batch)

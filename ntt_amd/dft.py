@@ -91,6 +91,10 @@ class _PlanTable(DFT):
         """Name of the arithmetic the plan's kernels use (nttx_plan_policy)."""
         return lib.nttx_plan_policy(self._plan).decode()
 
+    def feature(self, name):
+        """Whether the plan's kernels take the named shortcut (nttx_plan_feature)."""
+        return lib.nttx_plan_feature(self._plan, name.encode()) == 1
+
     def _run(self, x, forward, range_2q=False):
         if range_2q:
             host_fn = lib.nttx_forward_host_lazy if forward else lib.nttx_backward_host_lazy

