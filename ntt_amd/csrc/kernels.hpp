@@ -58,6 +58,8 @@ enum : uint32_t {
     PASS_LAZY = 1024u,         // outputs of the transform in the policy's lazy range ([0, 2q)) instead of canonical
     PASS_POW2_TWIDDLES = 4096u, // host side only: STRIDED 8-stage pass with s0 = 0 on a table whose entries 1..15 are the
                                // standard powers of two -- selects the kernel whose first radix-16 round multiplies by shifts
+    PASS_DEBUG_NO_MEM = 8192u,  // profiling aid (NTTX_DEBUG_NO_MEM=1): no global loads or stores of data -- registers are
+                               // filled with made-up residues and results dropped: the pass time with memory out of the picture
     PASS_DEBUG_HOT_TILES = 2048u // profiling aid (NTTX_DEBUG_HOT_TILES=1): every workgroup works on one of the first 64
                                // tiles, so all traffic is served by the L2s -- the pass time with HBM out of the picture
 };
@@ -484,6 +486,13 @@ __device__ __forceinline__ void buffer_store64(__amdgpu_buffer_rsrc_t r, uint32_
     __builtin_amdgcn_raw_buffer_store_b64(v, r, lane_bytes, uniform_bytes, AUX);
 }
 
+// Made-up residue (below 2^60) for element i of this thread: stands in for a load under PASS_DEBUG_NO_MEM.
+__device__ __forceinline__ uint64_t made_up_value(int i)
+{
+    const uint32_t h = (threadIdx.x * 2654435761u) ^ ((uint32_t)i * 40503u);
+    return pack64(h * 2246822519u, h & 0x0fffffffu);
+}
+
 // Tests a pass flag through an opaque scalar copy: the compiler then cannot tell that two tests
 // of the same flag agree, and does not clone everything between them for each outcome.
 __device__ __forceinline__ bool flag_set(uint32_t flags, uint32_t bit)
@@ -539,7 +548,11 @@ struct Round {
                                                 const typename A::Ctx& c) const
     {
         const uint32_t ss = safe_sigma(g);
-        if (flag_set(p.flags, PASS_OFFSET32)) {
+        if (NTTX_PROF(flag_set(p.flags, PASS_DEBUG_NO_MEM))) {
+#pragma unroll
+            for (int i = 0; i < M; i++)
+                x[i] = made_up_value(i);
+        } else if (flag_set(p.flags, PASS_OFFSET32)) {
             const __amdgpu_buffer_rsrc_t res = tile_resource(p.data + g.uniform_index());
             const uint32_t lane = (uint32_t)g.lane_index(ss, r0) * 8u;
             const uint32_t stepb = 8u << (g.logT + rstep_log);
@@ -559,7 +572,7 @@ struct Round {
     __device__ __forceinline__ void store_global(const uint64_t (&x)[M], const PassParams& p,
                                                  const Geom& g) const
     {
-        if (!ok)
+        if (!ok || NTTX_PROF(flag_set(p.flags, PASS_DEBUG_NO_MEM)))
             return;
         if (flag_set(p.flags, PASS_OFFSET32)) {
             const __amdgpu_buffer_rsrc_t res = tile_resource(p.data + g.uniform_index());
@@ -699,9 +712,12 @@ __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<
     };
     auto present = [&](int i) -> bool { return XB ? (fu(i) >> K) < left : fu(i) + fl < left; };
     const bool buffers = flag_set(p.flags, PASS_OFFSET32);
+    const bool no_mem = NTTX_PROF(flag_set(p.flags, PASS_DEBUG_NO_MEM));
     auto load_pair = [&](const uint64_t* from, int i) -> ulonglong2 {
         ulonglong2 v = make_ulonglong2(0, 0);
-        if (present(i)) {
+        if (no_mem) {
+            v = make_ulonglong2(made_up_value(2 * i), made_up_value(2 * i + 1));
+        } else if (present(i)) {
             if (buffers)
                 v = buffer_load128(tile_resource(from + first), fl * 8, (uint32_t)uniform_elems(i) * 8);
             else
@@ -741,7 +757,7 @@ __device__ __forceinline__ void copy_contig(const PassParams& p, const TileGeom<
     } else {
 #pragma unroll
         for (int i = 0; i < REGS / 2; i++) {
-            if (present(i)) {
+            if (present(i) && !no_mem) {
                 const uint64_t* const at = lds_of(i);
                 ulonglong2 v;
                 v.x = at[0];
@@ -1014,7 +1030,9 @@ __device__ __forceinline__ void move_runs(uint64_t (&x)[16], const PassParams& p
             for (int j = 0; j < 16; j++) {
                 const uint32_t run = 4 * w + (uint32_t)(j >> 2);
                 const uint64_t u = (run < left ? run : 0u) * run_stride + (uint32_t)(j & 3) * 64u;
-                if (buffers)
+                if (NTTX_PROF(flag_set(p.flags, PASS_DEBUG_NO_MEM)))
+                    t[j] = made_up_value(j);
+                else if (buffers)
                     t[j] = buffer_load64(tile_resource(from + first), lane * 8, (uint32_t)u * 8);
                 else
                     t[j] = from[first + u + lane];
@@ -1057,7 +1075,7 @@ __device__ __forceinline__ void move_runs(uint64_t (&x)[16], const PassParams& p
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
                 const int j = 4 * h + jj;
-                if (present(j)) {
+                if (present(j) && !NTTX_PROF(flag_set(p.flags, PASS_DEBUG_NO_MEM))) {
                     const uint64_t* const at = step_at(jj);
                     ulonglong2 v;
                     v.x = at[0];

@@ -294,7 +294,9 @@ int device_slot(const nttx_plan* plan, int device)
 //   NTTX_DEBUG_NO_TW=1         with NO_MATH: skip the twiddle loads too
 //   NTTX_DEBUG_NO_FINISH=1     skip the canonicalising end of the forward transform
 //   NTTX_DEBUG_HOT_TILES=1     every workgroup works on one of the first 64 tiles (all traffic from L2):
-//                              the pass time with HBM out of the picture
+//                              the pass time with HBM out of the picture (but 1000 workgroups store to the same lines)
+//   NTTX_DEBUG_NO_MEM=1        no global loads or stores of data at all (made-up inputs, results dropped):
+//                              the pass time with the memory system out of the picture
 //   NTTX_DEBUG_EXTRA_LDS=<b>   unused dynamic LDS per workgroup, to lower occupancy (launch_impl.hpp)
 // The shipped library contains none of the latter: no environment makes it return wrong results.
 struct Switches {
@@ -327,6 +329,8 @@ const Switches& switches()
             s.debug_flags |= PASS_DEBUG_NO_TW;
         if (std::getenv("NTTX_DEBUG_HOT_TILES"))
             s.debug_flags |= PASS_DEBUG_HOT_TILES;
+        if (std::getenv("NTTX_DEBUG_NO_MEM"))
+            s.debug_flags |= PASS_DEBUG_NO_MEM;
         s.no_finish = std::getenv("NTTX_DEBUG_NO_FINISH") != nullptr;
 #endif
         return s;
