@@ -613,6 +613,8 @@ struct Mont {
 // `res > q` (ntt_goldilock.rs:107) lets through.
 struct GoldilocksCtx {
     uint64_t n_inv; // plain residue (ntt_goldilock.rs:12)
+    uint32_t logn;  // log2 n when n_inv = 2^(192 - log2 n) is to be applied as a shift (plans with shift twiddles), else 0
+    uint32_t pad_;
 };
 
 struct Goldilocks {
@@ -859,17 +861,34 @@ struct Goldilocks {
     template <int K>
     static NTTX_HD uint64_t mul_pow2_fast(uint64_t a, uint32_t& top)
     {
-        static_assert(K > 0 && K < 96 && K % 32 != 0, "shift by a whole limb is not needed by any twiddle");
+        static_assert(K > 0 && K < 96, "0 < K < 96");
         constexpr int S = K % 32, J = K / 32;
         const uint32_t a0 = lo32(a), a1 = hi32(a);
-        const uint32_t y0 = a0 << S, y1 = (a1 << S) | (a0 >> (32 - S)), y2 = a1 >> (32 - S);
+        // S = 0: whole limbs, nothing to shift
+        const uint32_t y0 = S ? a0 << S : a0, y1 = S ? (a1 << S) | (a0 >> ((32 - S) & 31)) : a1, y2 = S ? a1 >> ((32 - S) & 31) : 0;
         if (J == 0)
             return reduce_limbs_fast(pack64(y0, y1), y2, top);        // y0 + 2^32 y1 + 2^64 y2
-        if (J == 1)
+        if (J == 1) {
+            if (S == 0)
+                return reduce_limbs_fast(pack64(0, y0), y1, top);     // 2^32 y0 + 2^64 y1
             return reduce_limbs_fast(pack64(0, y0), y1, y2, top);     // 2^32 y0 + 2^64 y1 + 2^96 y2
+        }
         // 2^64 y0 + 2^96 y1 + 2^128 y2 = y0 (2^32 - 1) - (y1 + 2^32 y2): both canonical (y2 < 2^31), so
         // the borrow-corrected difference is the canonical product exactly
         return sub_fast(mul_eps(y0), pack64(y1, y2), top);
+    }
+
+    // a * 2^-L mod q = a * 2^(192 - L) for 0 < L < 32 (the n^-1 of a transform of 2^L points): the limbs
+    // y0, y1, y2 of a << (32 - L) five limbs up, where 2^160 = 1 - 2^32, 2^192 = 1 and 2^224 = 2^32:
+    // (y0 + y1 + 2^32 y2) - 2^32 y0, both canonical, so the result is canonical exactly.
+    template <int L>
+    static NTTX_HD uint64_t mul_ninv_fast(uint64_t a, uint32_t& top)
+    {
+        static_assert(L > 0 && L < 32, "n = 2^L with 0 < L < 32");
+        constexpr int S = 32 - L;
+        const uint32_t a0 = lo32(a), a1 = hi32(a);
+        const uint32_t y0 = a0 << S, y1 = (a1 << S) | (a0 >> (32 - S)), y2 = a1 >> (32 - S);
+        return sub_fast(pack64(y1, y2) + y0, pack64(0, y0), top);
     }
 
     // Butterflies whose twiddle is 2^E, E in [0, 192) known at compile time; 2^E = -2^(E - 96) for
@@ -1022,6 +1041,19 @@ struct Goldilocks {
         const uint64_t u = a, v = b;
         a = add_strict(u, v);
         b = mul_strict(sub_gs_strict(u, v), s.w);
+    }
+
+    // The last inverse stage with both products as shifts, for a table with the standard powers of two:
+    // the sum times n^-1 = 2^(192 - L), the difference times tw_inv[1] * n^-1 = 2^144 * 2^(192 - L) =
+    // -2^(48 - L).  Operands in [0, q], as for gs_pow2_fast.
+    template <int L>
+    static NTTX_HD void gs_last_pow2_fast(uint64_t& a, uint64_t& b, uint32_t* tops)
+    {
+        static_assert(pow2_exponent(1, true) == 144 && L < 32, "tw_inv[1] = 2^144");
+        const uint64_t u = a, v = b;
+        uint32_t unused;
+        a = mul_ninv_fast<L>(add_fast(u, v, tops[0]), tops[1]);
+        b = mul_pow2_fast<48 - L>(sub_fast(v, u, unused), tops[2]);
     }
 
     // last stage + mul_reduce(., n_inv) (ntt_goldilock.rs:177-179): both products are canonical.

@@ -293,12 +293,31 @@ __device__ __forceinline__ void radix16_pow2(uint64_t (&x)[16], const Src& w, co
             }
         };
         if (last) {
-            const typename A::Tw s = A::scaled(w.get(1), c);
+            // n^-1 = 2^-log2(n) and the scaled stage-1 twiddle are powers of two as well; their exponents
+            // depend on n, so the sizes large batches come in have a compiled-in form each
+            auto shifted = [&](auto log_c) {
+                constexpr int L = decltype(log_c)::value;
 #pragma unroll
-            for (int i = 0; i < half; i++) {
-                uint32_t tops[3];
-                A::gs_last_fast(x[i], x[i + half], s, c, tops);
-                watch(tops, A::TOPS_GS_LAST);
+                for (int i = 0; i < half; i++) {
+                    uint32_t tops[3];
+                    A::template gs_last_pow2_fast<L>(x[i], x[i + half], tops);
+                    watch(tops, A::TOPS_GS_LAST);
+                }
+            };
+            switch (c.logn) {
+            case 16: shifted(std::integral_constant<int, 16>{}); break;
+            case 20: shifted(std::integral_constant<int, 20>{}); break;
+            case 24: shifted(std::integral_constant<int, 24>{}); break;
+            case 28: shifted(std::integral_constant<int, 28>{}); break;
+            default: {
+                const typename A::Tw s = A::scaled(w.get(1), c);
+#pragma unroll
+                for (int i = 0; i < half; i++) {
+                    uint32_t tops[3];
+                    A::gs_last_fast(x[i], x[i + half], s, c, tops);
+                    watch(tops, A::TOPS_GS_LAST);
+                }
+            }
             }
         } else {
             static_for<0, (1 << (u - 1))>([&](auto b_c) {

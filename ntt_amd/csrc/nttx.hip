@@ -1289,7 +1289,7 @@ int create_plan(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_inv, co
     plan->mctx = nttx::MontCtx{q, k, r_mod_q, n_inv};
     plan->mctx_mul = plan->mctx;
     plan->mctx_mul.n_inv_m = (uint64_t)(((u128)n_inv * r_mod_q) % q); // n^-1 * 2^128: REDC leaves n^-1 * 2^64
-    plan->gctx = nttx::GoldilocksCtx{n_inv};
+    plan->gctx = nttx::GoldilocksCtx{n_inv, 0, 0};
     const uint64_t psi_inv1 = src.seed ? src.seed_inv[1] : src.h_inv[1];
     if (plan->policy == nttx_plan::SHOUP61 || plan->policy == nttx_plan::SHOUP61_NEAR) {
         // The kernels multiply plain data by plain twiddles with a precomputed quotient; the constants
@@ -1303,7 +1303,7 @@ int create_plan(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_inv, co
     }
     if (plan->policy == nttx_plan::GOLDILOCKS_CANONICAL) {
         const ntt::utils::MontgomeryTransformer<uint64_t> mt{k, 0, q};
-        plan->gctx = nttx::GoldilocksCtx{mt.reduce((u128)n_inv)};
+        plan->gctx = nttx::GoldilocksCtx{mt.reduce((u128)n_inv), 0, 0};
     }
     if ((plan->policy == nttx_plan::GOLDILOCKS || plan->policy == nttx_plan::GOLDILOCKS_CANONICAL) && n >= 16 &&
         std::getenv("NTTX_NO_POW2_TWIDDLES") == nullptr) {
@@ -1320,6 +1320,9 @@ int create_plan(int kind, uint64_t q, uint64_t k, uint64_t n, uint64_t n_inv, co
                     bx == ntt::utils::mod_exp_u64(2, (uint64_t)nttx::Goldilocks::pow2_exponent(x, true), q);
         }
         plan->pow2_twiddles = match;
+        // with them n^-1 = 2^(192 - log2 n) can be a shift too (checked: n_inv is what the caller passed)
+        if (match && logn < 32 && plan->gctx.n_inv == ntt::utils::mod_exp_u64(2, 192 - logn, q))
+            plan->gctx.logn = logn;
     }
     int rc = guarded([&] {
         if (src.seed == 0) {

@@ -325,7 +325,7 @@ static void transform_tests(uint64_t q, uint64_t psi, size_t n, bool corrected =
 static void goldilocks_tests()
 {
     const uint64_t q = Goldilocks::Q;
-    GoldilocksCtx c{0x1234567812345678ull % q};
+    GoldilocksCtx c{0x1234567812345678ull % q, 0, 0};
     std::mt19937_64 rng(5);
     // values where a carry, a borrow or a compare against q is on the edge
     std::vector<uint64_t> edge = {0, 1, 2, q - 2, q - 1, q, q + 1, q + 2, ~0ull, ~0ull - 1, 0xffffffffull, 0xfffffffeull,
@@ -379,7 +379,7 @@ static void goldilocks_pow2_case(std::mt19937_64& rng, const std::vector<uint64_
 {
     const uint64_t q = Goldilocks::Q;
     const uint64_t w = ntt::utils::mod_exp_u64(2, E, q); // canonical 2^E: q - 2^(E-96) for E >= 96
-    GoldilocksCtx c{1};
+    GoldilocksCtx c{1, 0, 0};
     auto pick = [&](int it, int salt) -> uint64_t {
         switch ((it + salt) % 5) {
         case 0: return edge[rng() % edge.size()];
@@ -415,6 +415,34 @@ static void goldilocks_pow2_case(std::mt19937_64& rng, const std::vector<uint64_
         CHECK((x == xs && y == ys) || tops[0] == 0xffffffffu || tops[1] == 0xffffffffu);
     }
 }
+// the last inverse stage as shifts, for the transform sizes that have a compiled-in form
+template <int L>
+static void goldilocks_last_stage_case(std::mt19937_64& rng)
+{
+    const uint64_t q = Goldilocks::Q;
+    const uint64_t n_inv = ntt::utils::mod_exp_u64(2, 192 - L, q);
+    CHECK(mulmod(n_inv, 1ull << L, q) == 1);
+    GoldilocksCtx c{n_inv, L, 0};
+    const Goldilocks::Tw s1{ntt::utils::mod_exp_u64(2, 144, q)}; // tw_inv[1]
+    const Goldilocks::Tw sf = Goldilocks::scaled(s1, c);
+    const uint64_t edge[] = {0, 1, 2, q - 2, q - 1, q, 0xffffffffull, 0x100000000ull, 0xffffffff00000000ull, 0xfffffffeffffffffull};
+    for (int it = 0; it < 200000; it++) {
+        uint64_t a = it % 3 ? rng() % (q + 1) : edge[rng() % 10], b = it % 5 ? rng() % (q + 1) : edge[rng() % 10];
+        if (it % 13 == 0)
+            b = a; // zero difference
+        if (it % 17 == 0)
+            b = q - a; // sum of exactly q
+        uint32_t top;
+        const uint64_t m = Goldilocks::mul_ninv_fast<L>(a, top);
+        CHECK(m == Goldilocks::mul_strict(a, n_inv));
+        uint32_t tops[3];
+        uint64_t x = a, y = b, xs = a, ys = b;
+        Goldilocks::gs_last_pow2_fast<L>(x, y, tops);
+        Goldilocks::gs_last_strict(xs, ys, sf, c);
+        CHECK((x == xs && y == ys) || tops[0] == 0xffffffffu || tops[1] == 0xffffffffu || tops[2] == 0xffffffffu);
+    }
+}
+
 template <int... X>
 static void goldilocks_pow2_all(std::integer_sequence<int, X...>)
 {
@@ -432,6 +460,11 @@ static void goldilocks_pow2_all(std::integer_sequence<int, X...>)
         CHECK(t.powers_psi_inv_bo[x] == ntt::utils::mod_exp_u64(2, Goldilocks::pow2_exponent(x, true), q));
     }
     CHECK(t.powers_psi_bo[16] == Goldilocks::POW2_ROOT64);
+    goldilocks_last_stage_case<16>(rng);
+    goldilocks_last_stage_case<20>(rng);
+    goldilocks_last_stage_case<24>(rng);
+    goldilocks_last_stage_case<28>(rng);
+    goldilocks_last_stage_case<8>(rng);
 }
 
 int main()

@@ -17,7 +17,7 @@ for lib in "$@"; do
 import csv, glob, collections, re
 acc = collections.defaultdict(list)
 def short(n):
-    m = re.search(r"pass_kernel<nttx::([\w<>]+), (\w+), (\w+), (\d), (\d)(?:, (\w+))?>", n)
+    m = re.search(r"pass_kernel<nttx::([\w<>]+), (\w+), (\w+), (\d), (\d)(?:, \w+)*>", n)
     return None if not m else "%s %s" % ("fwd" if m.group(2) == "true" else "bwd", "contig" if m.group(3) == "true" else "strided")
 for f in glob.glob("$OUT/*/*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):

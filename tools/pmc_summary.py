@@ -7,7 +7,7 @@ for d in sys.argv[1:]:
             name = row["Kernel_Name"]
             if "pass_kernel" not in name:
                 continue
-            m = re.search(r"pass_kernel<nttx::(.+?), (\w+), (\w+), (\d), (\d)(?:, \w+)?>\(", name)
+            m = re.search(r"pass_kernel<nttx::(.+?), (\w+), (\w+), (\d), (\d)(?:, \w+)*>\(", name)
             short = "%s %s %s %s+%s" % (m.group(1), "fwd" if m.group(2) == "true" else "bwd",
                                         "contig" if m.group(3) == "true" else "strided", m.group(4), m.group(5))
             acc[(short, row["Counter_Name"])].append(float(row["Counter_Value"]))

@@ -19,7 +19,7 @@ def short(name):
     m = re.search(r"fused_small_kernel<nttx::(.+?), (\w+), (\d)>\(", name)
     if m:  # bench.py calls it "fwd fused 4+8 stages ..."
         return (m.group(1), "fwd" if m.group(2) == "true" else "bwd", "fused", int(m.group(3)), 8)
-    m = re.search(r"pass_kernel<nttx::(.+?), (\w+), (\w+), (\d), (\d)(?:, (\w+))?>\(", name)
+    m = re.search(r"pass_kernel<nttx::(.+?), (\w+), (\w+), (\d), (\d)(?:, \w+)*>\(", name)
     if not m:
         return None
     return (m.group(1), "fwd" if m.group(2) == "true" else "bwd", "contig" if m.group(3) == "true" else "strided",

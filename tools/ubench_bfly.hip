@@ -79,7 +79,7 @@ int main()
 {
     const uint64_t q = 0x1fffffffffe00001ull;
     MontCtx mc{q, 0x6000040000200001ull, (uint64_t)((((unsigned __int128)1) << 64) % q), 0x1000000000000ull};
-    GoldilocksCtx gc{0xfffeffff00010001ull};
+    GoldilocksCtx gc{0xfffeffff00010001ull, 0, 0};
     run<Mont<false>, true>("mont strict fwd", mc, q);
     run<Mont<false>, false>("mont strict bwd", mc, q);
     Shoup61Ctx sc = make_shoup61_ctx(q, 5, 7, 0);

@@ -9,7 +9,7 @@ import csv,glob,collections,re
 acc=collections.defaultdict(list)
 for f in glob.glob("gpurun_out/pmc_vpw/*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        m=re.search(r"pass_kernel<nttx::([\w<>]+), (\w+), (\w+), (\d), (\d), (\w+)>", row["Kernel_Name"])
+        m=re.search(r"pass_kernel<nttx::([\w<>]+), (\w+), (\w+), (\d), (\d)((?:, \w+)*)>", row["Kernel_Name"])
         if m: acc[(m.groups(), row["Counter_Name"])].append(float(row["Counter_Value"]))
 waves={k[0]:sum(v)/len(v) for k,v in acc.items() if k[1]=="SQ_WAVES"}
 for k,v in sorted(acc.items()):
