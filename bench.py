@@ -78,14 +78,26 @@ def rank_device(local_rank, allow_shared):
 
 
 def cpu_model():
+    """Model string of the host CPU with what /proc/cpuinfo adds to it (some hosts report a bare
+    "AMD EPYC"): family / model numbers, clock and the number of logical CPUs."""
+    fields = {}
+    logical = 0
     try:
         with open("/proc/cpuinfo") as fh:
             for line in fh:
-                if line.startswith("model name"):
-                    return line.split(":", 1)[1].strip()
+                if ":" not in line:
+                    continue
+                k, v = (t.strip() for t in line.split(":", 1))
+                if k == "processor":
+                    logical += 1
+                elif k in ("model name", "cpu family", "model", "cpu MHz") and k not in fields:
+                    fields[k] = v
     except OSError:
-        pass
-    return "unknown"
+        return "unknown"
+    if "model name" not in fields:
+        return "unknown"
+    return "%s (family %s model %s, %s MHz, %d logical CPUs on the host)" % (
+        fields["model name"], fields.get("cpu family", "?"), fields.get("model", "?"), fields.get("cpu MHz", "?"), logical)
 
 
 def kernel_source_stamp():
@@ -412,17 +424,21 @@ def main():
     di = kernels.index(dom)
     probe_out = torch.zeros(2, dtype=torch.int64, device=dev)
     side = torch.cuda.Stream(device=dev)
-    if di % npass == 0:
-        data.copy_(original)
-    torch.cuda.synchronize()
-    for r in range(12):
-        lib.nttx_run_pass_device(table._plan, local_rank, data.data_ptr(), batch, di // npass, di % npass, stream.cuda_stream)
-        if r == 2:
-            lib.nttx_clock_probe_device(local_rank, probe_out.data_ptr(), 2000, side.cuda_stream)
-    torch.cuda.synchronize()
-    cyc, ticks = (int(v) for v in probe_out.cpu())
-    if ticks > 0 and cyc > 0:
-        clock_mhz = 100.0 * cyc / ticks
+    readings = []
+    for _ in range(5):  # median of five 1 ms probes, each in the middle of six back-to-back launches
+        if di % npass == 0:
+            data.copy_(original)
+        torch.cuda.synchronize()
+        for r in range(6):
+            lib.nttx_run_pass_device(table._plan, local_rank, data.data_ptr(), batch, di // npass, di % npass, stream.cuda_stream)
+            if r == 1:
+                lib.nttx_clock_probe_device(local_rank, probe_out.data_ptr(), 1000, side.cuda_stream)
+        torch.cuda.synchronize()
+        cyc, ticks = (int(v) for v in probe_out.cpu())
+        if ticks > 0 and cyc > 0:
+            readings.append(100.0 * cyc / ticks)
+    if readings:
+        clock_mhz = sorted(readings)[len(readings) // 2]
     # leave `data` as the timed loop left it: these launches ran out of sequence
     data.copy_(original)
 
@@ -435,7 +451,7 @@ def main():
     if insts:
         ghz = (clock_mhz or 2400.0) / 1e3
         valu = {"wave_instructions_per_launch": insts, "clock_mhz": round(clock_mhz, 1) if clock_mhz else None,
-                "cycles_per_instruction": 4,
+                "cycles_per_instruction": 4,  # mean of the measured issue costs (2.5 for 32-bit adds / logic, 4.3-4.7 otherwise)
                 "issue_utilisation": round(insts * 4 / (dom["avg_ms"] * 1e-3 * 1024 * ghz * 1e9), 3),
                 "issue_utilisation_at_2400_mhz": round(insts * 4 / (dom["avg_ms"] * 1e-3 * 1024 * 2.4e9), 3)}
     elif clock_mhz:
