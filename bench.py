@@ -100,6 +100,42 @@ def cpu_model():
         fields["model name"], fields.get("cpu family", "?"), fields.get("model", "?"), fields.get("cpu MHz", "?"), logical)
 
 
+def board_power_sensor(torch, index):
+    """hwmon files of the card behind torch device `index`: (power in microwatts, its limit), or None.
+
+    amdgpu exposes the board's power as power1_average or power1_input and the limit the firmware holds
+    it to as power1_cap; the card is matched by PCI bus number, or taken when it is the only one."""
+    import glob
+    cards = []
+    for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        power = next((os.path.join(hw, f) for f in ("power1_average", "power1_input")
+                      if os.path.exists(os.path.join(hw, f))), None)
+        if power:
+            pci = os.path.basename(os.path.realpath(os.path.join(hw, "..", "..")))  # 0000:bb:dd.f
+            cards.append((pci, power, os.path.join(hw, "power1_cap")))
+    if not cards:
+        return None
+    if len(cards) == 1:
+        return cards[0][1:]
+    try:
+        bus = torch.cuda.get_device_properties(index).pci_bus_id
+    except Exception:
+        return None
+    for pci, power, cap in cards:
+        parts = pci.split(":")
+        if len(parts) == 3 and int(parts[1], 16) == bus:
+            return power, cap
+    return None
+
+
+def read_number(path):
+    try:
+        with open(path) as f:
+            return float(f.read().strip())
+    except (OSError, ValueError):
+        return None
+
+
 def kernel_source_stamp():
     """Hash of the kernel sources: PMC summaries under profiles/ carry the stamp of the sources they
     were measured on, and are only quoted while it matches."""
@@ -257,6 +293,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the round-trip checks (timing runs with the NTTX_DEBUG_* profiling switches, whose "
                          "results are meaningless on purpose); the record is marked invalid")
+    ap.add_argument("--no-power", action="store_true", help="skip the one-second board-power reading")
     ap.add_argument("--kernel-reps", type=int, default=10, help="event-timed launches per kernel for the roofline")
     ap.add_argument("--logn", type=int, default=0, help="goldilocks28split only: another (even) log2 n for rehearsals")
     args = ap.parse_args()
@@ -442,6 +479,38 @@ def main():
     # leave `data` as the timed loop left it: these launches ran out of sequence
     data.copy_(original)
 
+    # Board power under the timed loop's load.  The step is run back to back for about a second
+    # while a thread reads the card's power sensor; the second half of the readings (the sensor
+    # lags) against the limit the firmware enforces says whether the clock above is a power
+    # limit at work: at the limit, time goes with the energy a step costs, not with issue slots.
+    power = None
+    sensor = None if args.no_power else board_power_sensor(torch, local_rank)
+    if sensor:
+        import threading
+        samples, stop = [], threading.Event()
+
+        def sample():
+            while not stop.is_set():
+                w = read_number(sensor[0])
+                if w is not None:
+                    samples.append(w / 1e6)
+                time.sleep(0.02)
+
+        th = threading.Thread(target=sample)
+        th.start()
+        t_end = time.perf_counter() + 1.0
+        while time.perf_counter() < t_end:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+        stop.set()
+        th.join()
+        cap = read_number(sensor[1])
+        late = sorted(samples[len(samples) // 2:])
+        if late:
+            power = {"board_w": round(late[len(late) // 2], 1), "limit_w": round(cap / 1e6, 1) if cap else None,
+                     "samples": len(late), "source": "hwmon power1, second half of 1 s of back-to-back steps"}
+
     # second bound: integer VALU.  Wave-level VALU instructions per launch of that kernel
     # (SQ_INSTS_VALU); a wave64 instruction holds its SIMD for about 4 cycles (the multiplies and
     # 64-bit forms that make up most of a butterfly: tools/ubench_issue.hip) on 1024 SIMDs, priced at
@@ -469,7 +538,7 @@ def main():
         "bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom["avg_ms"], 4),
-        "whole_job_frac": round(frac_job, 4), "valu": valu, "floors": floors,
+        "whole_job_frac": round(frac_job, 4), "valu": valu, "floors": floors, "power": power,
         "kernels": [{"name": k["name"], "avg_ms": round(k["avg_ms"], 4)} for k in kernels],
     }
 
