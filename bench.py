@@ -100,14 +100,14 @@ def cpu_model():
         fields["model name"], fields.get("cpu family", "?"), fields.get("model", "?"), fields.get("cpu MHz", "?"), logical)
 
 
-def board_power_sensor(torch, index):
+def board_power_sensor(torch, index, root="/sys/class/drm"):
     """hwmon files of the card behind torch device `index`: (power in microwatts, its limit), or None.
 
     amdgpu exposes the board's power as power1_average or power1_input and the limit the firmware holds
     it to as power1_cap; the card is matched by PCI bus number, or taken when it is the only one."""
     import glob
     cards = []
-    for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+    for hw in sorted(glob.glob(os.path.join(root, "card*/device/hwmon/hwmon*"))):
         power = next((os.path.join(hw, f) for f in ("power1_average", "power1_input")
                       if os.path.exists(os.path.join(hw, f))), None)
         if power:

@@ -54,6 +54,8 @@ def test_two_ranks_weak():
     assert rec["config"]["batch_per_gpu"] == 64 and rec["config"]["job_batch"] == 128
     assert rec["value"] > 0 and rec["steps"] == 2
     assert abs(rec["value"] - 128 * 2 / (rec["ms_per_step"] * 2e-3)) / rec["value"] < 1e-3
+    power = rec["roofline"]["power"]  # read from the card's hwmon files where the box exposes them
+    assert power is None or (power["board_w"] > 0 and (power["limit_w"] is None or power["limit_w"] >= 100))
 
 
 def test_two_ranks_strong():
