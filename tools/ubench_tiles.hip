@@ -14,6 +14,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <vector>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(256) void xb_kernel(uint64_t* d, uint32_t s0 /* log
 }
 
 // strided tile, both sides A8 (as the first forward / last backward pass); G > 0: XCD-grouped order
+template <int LAUX = NT, int SAUX = NT>
 __global__ __launch_bounds__(256) void strided_kernel(uint64_t* d, uint32_t G)
 {
     uint64_t tile = blockIdx.x;
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(256) void strided_kernel(uint64_t* d, uint32_t G)
     uint64_t v[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const u32x2_t x = __builtin_amdgcn_raw_buffer_load_b64(r, lane, i * 16 * 256 * 8, NT);
+        const u32x2_t x = __builtin_amdgcn_raw_buffer_load_b64(r, lane, i * 16 * 256 * 8, LAUX);
         v[i] = ((uint64_t)x.y << 32) | x.x;
     }
 #pragma unroll
@@ -109,9 +115,26 @@ __global__ __launch_bounds__(256) void strided_kernel(uint64_t* d, uint32_t G)
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const u32x2_t x = {(uint32_t)v[i], (uint32_t)(v[i] >> 32)};
-        __builtin_amdgcn_raw_buffer_store_b64(x, r, lane2, i * 256 * 8, NT);
+        __builtin_amdgcn_raw_buffer_store_b64(x, r, lane2, i * 256 * 8, SAUX);
     }
 }
+
+static double board_watts()
+{
+    FILE* f = fopen("/sys/class/drm/card0/device/hwmon/hwmon0/power1_input", "r");
+    if (!f)
+        return 0;
+    long long uw = 0;
+    if (fscanf(f, "%lld", &uw) != 1)
+        uw = 0;
+    fclose(f);
+    return uw / 1e6;
+}
+
+// `ubench_tiles power`: every shape runs back to back for 0.7 s while the board power (hwmon) is sampled
+// every 20 ms; the plateau (median of the second half) is printed beside the rate.
+static bool with_power = false;
+static double run_seconds = 0.7;
 
 template <class F> void timeit(const char* name, F launch, double bytes)
 {
@@ -119,6 +142,35 @@ template <class F> void timeit(const char* name, F launch, double bytes)
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int r = 0; r < 3; r++) launch();
     CHECK(hipDeviceSynchronize());
+    if (with_power) {
+        std::atomic<bool> stop{false};
+        std::vector<double> watts;
+        std::thread sampler([&] {
+            while (!stop.load()) {
+                watts.push_back(board_watts());
+                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            }
+        });
+        const auto t0 = std::chrono::steady_clock::now();
+        int launches = 0;
+        CHECK(hipEventRecord(e0));
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < run_seconds) {
+            for (int r = 0; r < 8; r++, launches++)
+                launch();
+            CHECK(hipDeviceSynchronize());
+        }
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        stop.store(true);
+        sampler.join();
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<double> late(watts.begin() + watts.size() / 2, watts.end());
+        std::sort(late.begin(), late.end());
+        const double w = late.empty() ? 0 : late[late.size() / 2];
+        const double tbs = bytes * launches / (ms * 1e-3) / 1e12;
+        printf("%-44s %4d launches  %.3f ms each  -> %.2f TB/s (read+write)  %5.0f W  %5.1f W per TB/s above 360 W\n", name, launches,
+               ms / launches, tbs, w, (w - 360) / tbs);
+        return;
+    }
     float best = 1e9, sum = 0;
     const int reps = 10;
     for (int r = 0; r < reps; r++) {
@@ -128,17 +180,49 @@ template <class F> void timeit(const char* name, F launch, double bytes)
     printf("%-44s best %.3f ms  avg %.3f ms  -> %.2f TB/s (read+write)\n", name, best, sum / reps, bytes / (sum / reps * 1e-3) / 1e12);
 }
 
-int main()
+// `ubench_tiles aux`: the strided tile (XCD groups of 16) and the cross-batch tile (C8 loads, A8 stores) under every
+// pair of cache policies of the buffer instructions (aux bits: 1 = sc0, 2 = nt, 16 = sc1), with board power.
+template <int L, int S> void aux_case(uint64_t* d, unsigned grid, double bytes)
 {
+    char name[64];
+    snprintf(name, sizeof name, "strided  load aux %2d  store aux %2d", L, S);
+    timeit(name, [&] { strided_kernel<L, S><<<grid, 256>>>(d, 16); }, bytes);
+    snprintf(name, sizeof name, "xb C8->A8  load aux %2d  store aux %2d", L, S);
+    timeit(name, [&] { xb_kernel<C8, A8, L, S><<<grid, 256>>>(d, 8); }, bytes);
+}
+template <int L> void aux_row(uint64_t* d, unsigned grid, double bytes)
+{
+    aux_case<L, 0>(d, grid, bytes);
+    aux_case<L, 1>(d, grid, bytes);
+    aux_case<L, 2>(d, grid, bytes);
+    aux_case<L, 3>(d, grid, bytes);
+    aux_case<L, 16>(d, grid, bytes);
+    aux_case<L, 18>(d, grid, bytes);
+}
+
+int main(int argc, char** argv)
+{
+    with_power = argc > 1 && argv[1][0] == 'p';
     const size_t n = (size_t)4096 * 65536;
     uint64_t* d;
     CHECK(hipMalloc(&d, n * 8));
     CHECK(hipMemset(d, 1, n * 8));
     const double bytes = 2.0 * n * 8;
     const unsigned grid = (unsigned)(n / 4096);
-    for (int round = 0; round < 2; round++) {
-        timeit("strided A8 -> A8, plain order", [&] { strided_kernel<<<grid, 256>>>(d, 0); }, bytes);
-        timeit("strided A8 -> A8, XCD groups of 16", [&] { strided_kernel<<<grid, 256>>>(d, 16); }, bytes);
+    if (argc > 1 && argv[1][0] == 'a') {
+        with_power = true;
+        run_seconds = 0.45;
+        aux_row<0>(d, grid, bytes);
+        aux_row<1>(d, grid, bytes);
+        aux_row<2>(d, grid, bytes);
+        aux_row<3>(d, grid, bytes);
+        aux_row<16>(d, grid, bytes);
+        aux_row<18>(d, grid, bytes);
+        return 0;
+    }
+    for (int round = 0; round < (with_power ? 1 : 2); round++) {
+        timeit("strided A8 -> A8, plain order", [&] { strided_kernel<><<<grid, 256>>>(d, 0); }, bytes);
+        timeit("strided A8 -> A8, XCD groups of 16", [&] { strided_kernel<><<<grid, 256>>>(d, 16); }, bytes);
         timeit("xb A8 -> C16 (fwd contig as shipped)", [&] { xb_kernel<A8, C16><<<grid, 256>>>(d, 8); }, bytes);
         timeit("xb A8 -> C8", [&] { xb_kernel<A8, C8><<<grid, 256>>>(d, 8); }, bytes);
         timeit("xb A8 -> A8", [&] { xb_kernel<A8, A8><<<grid, 256>>>(d, 8); }, bytes);
