@@ -210,6 +210,7 @@ def run_split(args, json_fd):
     def step(x):
         return st.backward(st.forward(x))
 
+    barrier()  # the process's first barrier pays its set-up here, not in front of the timed region
     col = step(col)
     if not torch.equal(col, original):
         raise SystemExit("round trip failure")
@@ -400,6 +401,10 @@ def main():
         table.forward_inplace(data)
         table.backward_inplace(data)
 
+    # The first collective of a process pays the communicator's set-up (tens of milliseconds with the GPU
+    # idle); taken here, the barrier in front of the timed region is a warm one (~30 us) and the chip, which
+    # runs this step at its power limit, enters the timed region in the state the warm-up left it in.
+    barrier()
     for _ in range(5):  # settle clocks and caches before the counted warm-up, whatever W is
         step()
     for _ in range(args.warmup):
