@@ -24,6 +24,8 @@ def test_reference_known_answers():
     assert avx2.a_lt_b([1, 1, -1, -2], [2, -1, 1, -1]) == [-1, -1, 0, -1]                  # :926-939
     assert avx2.a_lt_b([2, -1, 1, -1], [1, 1, -1, -2]) == [0, 0, -1, 0]
     assert avx2.extract_m256i_to_i64([1, -1, 2**63, 2**64 - 1]) == [1, -1, -2**63, -1]
+    assert avx2.extract_m256i_to_i64([1, 2, 3, 4]) == [1, 2, 3, 4]                          # :856-862
+    assert avx2.extract_m256d_to_f64([1.0, 2.0, 3.0, 4.0]) == [1.0, 2.0, 3.0, 4.0]          # :865-872
 
 
 def test_python_mirror_matches_oracle_intrinsics():

@@ -159,6 +159,36 @@ def test_goldilock_correctness(amd):  # dft.rs:127-152
     assert np.array_equal(a, a_cloned)
 
 
+def test_avx_against_base(amd):  # dft.rs:81-124: ten forward + backward rounds on each table return the input
+    table, table_avx = amd.Table.new(), amd.TableAVX2.new()
+    a_avx2 = orc.splitmix_residues(table_avx.q, 1 << 16, 15).astype(np.int64)
+    a = a_avx2.astype(np.uint64)
+    a_cloned = a.copy()
+    for _ in range(10):
+        table.forward_inplace(a)
+        table.backward_inplace(a)
+    assert np.array_equal(a, a_cloned)
+    for _ in range(10):
+        table_avx.forward_inplace(a_avx2)
+        table_avx.backward_inplace(a_avx2)
+    assert np.array_equal(a_cloned, a_avx2.view(np.uint64))
+
+
+def test_goldilock_against_base(amd):  # dft.rs:155-189
+    table, table_goldilock = amd.Table.new_goldilock(), amd.TableGoldilock.new()
+    a_goldilock = orc.splitmix_residues(table_goldilock.q, 1 << 16, 16)
+    a = a_goldilock.copy()
+    a_cloned = a.copy()
+    for _ in range(10):
+        table.forward_inplace(a)
+        table.backward_inplace(a)
+    for _ in range(10):
+        table_goldilock.forward_inplace(a_goldilock)
+        table_goldilock.backward_inplace(a_goldilock)
+    assert np.array_equal(a_cloned, a)
+    assert np.array_equal(a_cloned, a_goldilock)
+
+
 def test_normal_case(amd):  # ntt.rs:279-295 (`2 ^ 61` is XOR: inputs in 0..63)
     table = amd.Table.new()
     a = (orc.splitmix_residues(Q61, 1 << 16, 14) % np.uint64(63)).astype(np.uint64)

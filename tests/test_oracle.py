@@ -301,6 +301,34 @@ def test_goldilock_correctness():  # dft.rs:127-152
     assert np.array_equal(a, a0)
 
 
+def test_avx_against_base():  # dft.rs:81-124: ten forward + backward rounds on each table return the input
+    t, tv = orc.Table.new(), orc.TableAVX2.new()
+    a0 = orc.splitmix_residues(Q61, 1 << 16, 5)
+    a, av = a0.copy(), a0.astype(np.int64)
+    for _ in range(10):
+        t.forward_inplace(a)
+        t.backward_inplace(a)
+    assert np.array_equal(a, a0)
+    for _ in range(10):
+        tv.forward_inplace(av)
+        tv.backward_inplace(av)
+    assert np.array_equal(av.view(np.uint64), a0)
+
+
+def test_goldilock_against_base():  # dft.rs:155-189: the same for the Goldilocks prime on both tables
+    t, tg = orc.Table.new_goldilock(), orc.TableGoldilock.new()
+    a0 = orc.splitmix_residues(QGL, 1 << 16, 6)
+    a, ag = a0.copy(), a0.copy()
+    for _ in range(10):
+        t.forward_inplace(a)
+        t.backward_inplace(a)
+    for _ in range(10):
+        tg.forward_inplace(ag)
+        tg.backward_inplace(ag)
+    assert np.array_equal(a, a0)
+    assert np.array_equal(ag, a0)  # the reference stops at the base table; the round trip holds here too
+
+
 def test_normal_case():  # ntt.rs:279-295; `2 ^ 61` there is XOR, i.e. inputs in 0..63
     t = orc.Table.new()
     a0 = (orc.splitmix_residues(Q61, 1 << 16, 4) % np.uint64(63)).astype(np.uint64)
