@@ -10,8 +10,10 @@ from bench import kernel_source_stamp  # the stamp bench.py checks before quotin
 tag, workload = sys.argv[1], sys.argv[2]
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
-for f in glob.glob(src + "/trace/*/*kernel_stats.csv"):
-    shutil.copy(f, "profiles/%s_kernel_stats.csv" % tag)
+# gpurun_out/ keeps the files of earlier collections (one per process id): take the newest
+stats = sorted(glob.glob(src + "/trace/*/*kernel_stats.csv"), key=os.path.getmtime)
+if stats:
+    shutil.copy(stats[-1], "profiles/%s_kernel_stats.csv" % tag)
 shutil.copy(src + "/bench.json", "profiles/%s_bench.json" % tag)
 
 
