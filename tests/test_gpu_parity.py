@@ -94,6 +94,25 @@ def test_goldilocks_prime_through_montgomery_table(amd, logn):
     _batch_check(gpu, ref, QGL, n, 3, 3000 + logn)
 
 
+@pytest.mark.parametrize("logn", [22, 24])
+def test_sizes_between_the_benchmark_ones(amd, logn):
+    """2^22 = a 6-stage first pass, then 8 + 8; 2^24 = three 8-stage passes: pass plans no benchmark size takes.
+    One vector and a pair, both table kinds; the forward output and the round trip against the oracle."""
+    n = 1 << logn
+    psi = psigl_for(n)
+    for gpu, ref, q in ((amd.TableGoldilock.from_root(psi, n), orc.TableGoldilock.from_root(psi, n), QGL),
+                        (amd.Table.from_prime_and_root(QGL, psi, n), orc.Table.from_prime_and_root(QGL, psi, n), QGL)):
+        for batch in (1, 2):
+            x = orc.splitmix_residues(q, n * batch, 2200 + logn + batch)
+            a, w = x.copy(), x.copy()
+            gpu.forward_inplace_batch(a, batch)
+            for b in range(batch):
+                ref.forward_inplace(w[b * n:(b + 1) * n])
+            assert np.array_equal(a, w), ("forward", logn, batch)
+            gpu.backward_inplace_batch(a, batch)
+            assert np.array_equal(a, x), ("round trip", logn, batch)
+
+
 def test_two_to_the_26_goldilocks(amd):
     """log2 n = 2 mod 8 above 2^18: two 8-stage passes, then the last 10 stages in one launch."""
     n = 1 << 26
