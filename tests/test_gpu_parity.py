@@ -416,6 +416,62 @@ def test_device_resident_batch(amd):
     assert np.array_equal(dev.cpu().numpy().view(np.uint64), host)
 
 
+def test_cross_batch_tiles_at_the_32_bit_offset_limit(amd):
+    """Sixteen 2^24-point transforms: the cross-batch tile of the last pass spans 2^31 bytes, the largest span the
+    32-bit lane and run offsets of its buffer addressing may cover.  First, middle and last transform against the
+    oracle; the backward transform restores every element."""
+    import torch
+
+    n, batch = 1 << 24, 16
+    psi = psigl_for(n)
+    t, ref = amd.TableGoldilock.from_root(psi, n), orc.TableGoldilock.from_root(psi, n)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(2431)
+    hi = torch.randint(0, 2**32 - 1, (n * batch,), dtype=torch.int64, device="cuda", generator=gen)  # below q
+    lo = torch.randint(0, 2**32, (n * batch,), dtype=torch.int64, device="cuda", generator=gen)
+    dev = (hi << 32) | lo
+    del hi, lo
+    original = dev.clone()
+    t.forward_inplace(dev)
+    torch.cuda.synchronize()
+    for b in (0, 7, 15):
+        w = original[b * n:(b + 1) * n].cpu().numpy().view(np.uint64).copy()
+        ref.forward_inplace(w)
+        assert np.array_equal(dev[b * n:(b + 1) * n].cpu().numpy().view(np.uint64), w), b
+    t.backward_inplace(dev)
+    torch.cuda.synchronize()
+    assert torch.equal(dev, original)
+
+
+def test_cross_batch_tiles_beyond_32_bit_offsets(amd):
+    """Sixteen 2^26-point transforms (8 GiB): a cross-batch tile of the last pass spans 2^33 bytes, so its runs are
+    addressed through 64-bit pointers instead of a buffer resource.  First and last transform against the oracle;
+    the backward transform restores every element."""
+    import torch
+
+    n, batch = 1 << 26, 16
+    psi = psigl_for(n)
+    t, ref = amd.TableGoldilock.from_root(psi, n), orc.TableGoldilock.from_root(psi, n)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(2633)
+    hi = torch.randint(0, 2**32 - 1, (n * batch,), dtype=torch.int64, device="cuda", generator=gen)  # below q
+    lo = torch.randint(0, 2**32, (n * batch,), dtype=torch.int64, device="cuda", generator=gen)
+    dev = (hi << 32) | lo
+    del hi, lo
+    original = dev.clone()
+    t.forward_inplace(dev)
+    torch.cuda.synchronize()
+    for b in (0, 15):
+        w = original[b * n:(b + 1) * n].cpu().numpy().view(np.uint64).copy()
+        ref.forward_inplace(w)
+        assert np.array_equal(dev[b * n:(b + 1) * n].cpu().numpy().view(np.uint64), w), b
+    t.backward_inplace(dev)
+    torch.cuda.synchronize()
+    assert torch.equal(dev, original)
+    del dev, original
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("workload", ["mont16", "goldilocks20"])
 def test_baseline_sizes_device_resident(amd, workload):
     """BASELINE.json configs[1] / configs[2] at full size on the device: sampled transforms against
