@@ -416,6 +416,42 @@ def test_device_resident_batch(amd):
     assert np.array_equal(dev.cpu().numpy().view(np.uint64), host)
 
 
+def test_two_to_the_30_goldilocks_by_closed_form(amd):
+    """One 2^30-point transform (8 GiB): blocks of the first pass exceed the 2^31 bytes a buffer resource's offsets
+    cover, so its tiles are addressed through 64-bit pointers.  The oracle would need minutes here; the input is a
+    constant c0 (dense: every butterfly of every stage works on non-zero data) plus two scaled unit vectors, whose
+    transform is A[i] = -2 c0 / (psi^e - 1) + c1 psi^(j1 e) + c2 psi^(j2 e), e = 2 brev(i) + 1 (the transform's
+    definition, ntt.rs:129-171 unrolled, with psi^n = -1), checked at 3000 sampled outputs; the backward transform
+    restores the input."""
+    import torch
+
+    logn = 30
+    n = 1 << logn
+    psi = psigl_for(n)
+    t = amd.TableGoldilock.from_root(psi, n)
+    j1, j2, c0, c1, c2 = 3, n - 5, 0xFEDCBA9876543 % QGL, 0x123456789ABCDEF % QGL, QGL - 2
+    as_i64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v
+    dev = torch.full((n,), as_i64(c0), dtype=torch.int64, device="cuda")
+    dev[j1], dev[j2] = as_i64((c0 + c1) % QGL), as_i64((c0 + c2) % QGL)
+    t.forward_inplace(dev)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(30)
+    idx = np.unique(np.concatenate([[0, 1, 2, n // 2, n - 2, n - 1], rng.integers(0, n, 3000)]))
+    got = dev[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint64)
+    for i, g in zip(idx.tolist(), got.tolist()):
+        e = 2 * int(format(i, "0%db" % logn)[::-1], 2) + 1
+        dense = -2 * c0 * pow(pow(psi, e, QGL) - 1, QGL - 2, QGL)
+        want = (dense + c1 * pow(psi, j1 * e, QGL) + c2 * pow(psi, j2 * e, QGL)) % QGL
+        assert g % QGL == want and g <= QGL, i   # the forward transform may leave q for 0 (ntt_goldilock.rs:107)
+    t.backward_inplace(dev)
+    torch.cuda.synchronize()
+    assert int(dev[j1]) == as_i64((c0 + c1) % QGL) and int(dev[j2]) == as_i64((c0 + c2) % QGL)
+    dev[j1], dev[j2] = as_i64(c0), as_i64(c0)
+    assert int(torch.count_nonzero(dev - as_i64(c0))) == 0
+    del dev
+    torch.cuda.empty_cache()
+
+
 def test_cross_batch_tiles_at_the_32_bit_offset_limit(amd):
     """Sixteen 2^24-point transforms: the cross-batch tile of the last pass spans 2^31 bytes, the largest span the
     32-bit lane and run offsets of its buffer addressing may cover.  First, middle and last transform against the
