@@ -2,7 +2,7 @@
 //! `Table<u64>` (src/dft/ntt.rs:122-236), `TableAVX2` (src/dft/ntt_avx2.rs:108-470) and
 //! `TableGoldilock<u64>` (src/dft/ntt_goldilock.rs:81-180) when the crate is built against libnttx.
 //!
-//! How a maintainer applies it (INTEGRATION.md has the same steps with the reasons):
+//! How a maintainer applies it:
 //!   1. each struct gains one private field, `plan: Option<crate::ffi::Plan>`, initialised to `None`
 //!      where the struct literal is written (ntt.rs:106-116, ntt_avx2.rs:91-101,
 //!      ntt_goldilock.rs:49-57);
