@@ -80,6 +80,22 @@ static void exercise(int kind, uint64_t q, uint64_t psi, uint64_t n, const char*
         std::vector<uint64_t> too_big((40u << 20) / 8);
         CHECK(nttx_transform_host_noalloc(plan, too_big.data(), too_big.size() / n, 0) == NTTX_EINVAL);
     }
+    { // one plan, four host threads at once: small calls and a streamed one
+        auto work = [&](uint64_t seed, size_t batch) {
+            std::vector<uint64_t> x = residues(q, n * batch, seed), y = x;
+            for (int rep = 0; rep < 3; rep++) {
+                CHECK(nttx_forward_host(plan, y.data(), batch) == NTTX_OK);
+                CHECK(nttx_backward_host(plan, y.data(), batch) == NTTX_OK);
+            }
+            CHECK(y == x);
+        };
+        const size_t streamed = (20u << 20) / (n * 8) + 1;
+        std::thread t1(work, 31, 1), t2(work, 32, 2), t3(work, 33, streamed), t4(work, 34, 3);
+        t1.join();
+        t2.join();
+        t3.join();
+        t4.join();
+    }
     if (n >= (1u << 16)) { // split transform on virtual shards of the one device
         for (int shards : {2, 4}) {
             std::vector<uint64_t> x = residues(q, n, 21 + shards), y = x, z = x;

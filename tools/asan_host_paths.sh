@@ -4,6 +4,7 @@
 # into tools/bin/.
 # Build here:       [SAN=undefined] tools/asan_host_paths.sh build
 # Run on a GPU box: [SAN=undefined] tools/asan_host_paths.sh run
+# (ThreadSanitizer builds the same way but its runtime does not start on the GPU boxes: it exits at once, silently.)
 set -e
 cd "$(dirname "$0")/.."
 CLANG=/opt/rocm/lib/llvm/bin/clang++
@@ -22,10 +23,10 @@ run)
   # Verdict from the output, not the exit status: at process exit the HSA runtime's own teardown can trip an internal
   # check of the sanitizer's device allocator (frames in libhsa-runtime64 under __cxa_finalize), after our code is done.
   out=$(mktemp)
-  timeout -k 10 300 tools/bin/host_paths_$SAN > $out 2>&1; cat $out
+  timeout -k 10 300 tools/bin/host_paths_$SAN > $out 2>&1 || true; cat $out
   grep -q "host paths clean" $out || exit 1
   ! grep -q "ERROR: AddressSanitizer\|runtime error:" $out || exit 1
-  timeout -k 10 300 tools/bin/test_dft_$SAN > $out 2>&1; cat $out
+  timeout -k 10 300 tools/bin/test_dft_$SAN > $out 2>&1 || true; cat $out
   grep -q "all host-mirror tests passed" $out || exit 1
   ! grep -q "ERROR: AddressSanitizer\|runtime error:" $out || exit 1
   echo "sanitizer run ($SAN): clean"
