@@ -602,6 +602,10 @@ def test_abi_argument_checks(amd):
     assert b"aligned" in lib.nttx_last_error()
     assert lib.nttx_forward_device(t._plan, 5, buf.data_ptr(), 1, None) == _lib.NTTX_ENODEV       # not a plan device
     assert lib.nttx_forward_device(t._plan, 0, buf.data_ptr(), 0, None) == _lib.NTTX_OK           # empty batch
+    for batch in (1 << 30, 1 << 60):   # batch * n beyond 2^40 elements / beyond 64 bits: refused before any launch
+        assert lib.nttx_forward_device(t._plan, 0, buf.data_ptr(), batch, None) == _lib.NTTX_EINVAL
+        assert b"too large" in lib.nttx_last_error()
+        assert lib.nttx_backward_device(t._plan, 0, buf.data_ptr(), batch, None) == _lib.NTTX_EINVAL
     assert lib.nttx_forward_host(t._plan, None, 1) == _lib.NTTX_EINVAL
     assert lib.nttx_forward_host(t._plan, None, 0) == _lib.NTTX_OK
     assert lib.nttx_run_pass_device(t._plan, 0, buf.data_ptr(), 1, 0, 7, None) == _lib.NTTX_EINVAL
