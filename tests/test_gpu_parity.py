@@ -416,7 +416,8 @@ def test_device_resident_batch(amd):
     assert np.array_equal(dev.cpu().numpy().view(np.uint64), host)
 
 
-def test_two_to_the_30_goldilocks_by_closed_form(amd):
+@pytest.mark.parametrize("kind", ["goldilock", "montgomery"])
+def test_two_to_the_30_goldilocks_by_closed_form(amd, kind):
     """One 2^30-point transform (8 GiB): blocks of the first pass exceed the 2^31 bytes a buffer resource's offsets
     cover, so its tiles are addressed through 64-bit pointers.  The oracle would need minutes here; the input is a
     constant c0 (dense: every butterfly of every stage works on non-zero data) plus two scaled unit vectors, whose
@@ -428,7 +429,8 @@ def test_two_to_the_30_goldilocks_by_closed_form(amd):
     logn = 30
     n = 1 << logn
     psi = psigl_for(n)
-    t = amd.TableGoldilock.from_root(psi, n)
+    # TableGoldilock, and the same prime as a Montgomery table (Table::new_goldilock's kind, ntt.rs:60-62)
+    t = amd.TableGoldilock.from_root(psi, n) if kind == "goldilock" else amd.Table.from_prime_and_root(QGL, psi, n)
     j1, j2, c0, c1, c2 = 3, n - 5, 0xFEDCBA9876543 % QGL, 0x123456789ABCDEF % QGL, QGL - 2
     as_i64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v
     dev = torch.full((n,), as_i64(c0), dtype=torch.int64, device="cuda")
