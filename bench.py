@@ -423,30 +423,36 @@ def main():
     frac_job = value * 32 * N / (distinct * HBM_PEAK_GBS * 1e9)
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, per pass -----------
+    # The step is issued again pass by pass (nttx_run_pass_device, the same launches in the same order as
+    # the two calls of step() make), back to back with an event between consecutive launches and no
+    # synchronisation until the end: every kernel is timed in the sequence and at the power state of the
+    # timed region, not in isolation (an isolated launch starts with power headroom and runs 1-9 % faster).
     stream = torch.cuda.current_stream(dev)
     npass = lib.nttx_pass_count(table._plan)
-    kernels = []
+    names = []
     for direction in (0, 1):
         for pi in range(npass):
             buf = C.create_string_buffer(96)
             lib.nttx_pass_describe(table._plan, direction, pi, buf, 96)
-            evs = []
-            for r in range(args.kernel_reps + 2):
-                if pi == 0:
-                    # the first pass of a transform screens its input for values >= q; feed it
-                    # residues, as the full transform does, not the previous launch's output
-                    data.copy_(original)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                rc = lib.nttx_run_pass_device(table._plan, local_rank, data.data_ptr(), batch, direction, pi,
-                                              stream.cuda_stream)
-                e1.record(stream)
-                if rc != 0:
-                    raise SystemExit("nttx_run_pass_device failed")
-                evs.append((e0, e1))
-            torch.cuda.synchronize()
-            ms = [a.elapsed_time(b) for a, b in evs[2:]]
-            kernels.append({"name": buf.value.decode(), "avg_ms": sum(ms) / len(ms)})
+            names.append((direction, pi, buf.value.decode()))
+    reps = max(args.kernel_reps, 1) + 2
+    marks = []
+    for r in range(reps):
+        row = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
+        row[0].record(stream)
+        for i, (direction, pi, _) in enumerate(names):
+            rc = lib.nttx_run_pass_device(table._plan, local_rank, data.data_ptr(), batch, direction, pi, stream.cuda_stream)
+            if rc != 0:
+                raise SystemExit("nttx_run_pass_device failed")
+            row[i + 1].record(stream)
+        marks.append(row)
+    torch.cuda.synchronize()
+    if not torch.equal(data, original) and not args.no_verify:
+        raise SystemExit("the passes issued one by one do not add up to the transform pair")
+    kernels = []
+    for i, (_, _, name) in enumerate(names):
+        ms = [row[i].elapsed_time(row[i + 1]) for row in marks[2:]]
+        kernels.append({"name": name, "avg_ms": sum(ms) / len(ms)})
     dom = max(kernels, key=lambda k: k["avg_ms"])
     # algorithmic bytes: 16*N per transform (8N read + 8N written once), apportioned to a launch
     # by the share of the log2(N) stages it executes ("... stages a-b" in the pass name)
