@@ -1,6 +1,7 @@
 """Randomised parity sweep (test helper): random table kinds, sizes, batches and inputs -- residues,
-arbitrary u64, lazily reduced and edge values -- through the host entry points, the split transform
-and the negacyclic product, each compared with the CPU oracle.  tests/test_gpu_fuzz.py runs a
+arbitrary u64, lazily reduced and edge values -- through the host entry points, the device entry points
+(batches resident on the GPU, on a random stream), the [0, 2q) opt-in, the split transform and the
+negacyclic product, each compared with the CPU oracle.  tests/test_gpu_fuzz.py runs a
 bounded, seeded slice; tests/manual/fuzz_parity.py runs it for as long as asked."""
 import time
 
@@ -75,7 +76,7 @@ def run(budget, seed, progress=False):
         n = 1 << logn
         batch = int(rng.integers(1, 70 if logn <= 14 else (24 if logn <= 16 else 3)))
         gpu, ref, q = get(kind, logn)
-        mode = int(rng.integers(0, 4))
+        mode = int(rng.integers(0, 6))
         style = int(rng.integers(0, 4))
         a = inputs(q, n * batch, style)
         tag = (kind, logn, batch, mode, style)
@@ -91,6 +92,32 @@ def run(budget, seed, progress=False):
                 ref.backward_inplace(w[b * n:(b + 1) * n])
             gpu.backward_inplace_batch(a, batch)
             assert np.array_equal(a, w), tag
+        elif mode == 4:    # device-resident batch on a stream of its own: forward, then backward, both against the oracle
+            import torch
+            w = a.copy()
+            for b in range(batch):
+                ref.forward_inplace(w[b * n:(b + 1) * n])
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                d = torch.from_numpy(a.view(np.int64)).cuda()
+                gpu.forward_inplace(d)
+                f = d.cpu().numpy().view(np.uint64).copy()
+                gpu.backward_inplace(d)
+                r = d.cpu().numpy().view(np.uint64).copy()
+            assert np.array_equal(f, w), tag
+            for b in range(batch):
+                ref.backward_inplace(w[b * n:(b + 1) * n])
+            assert np.array_equal(r, w), tag
+        elif mode == 5:    # outputs in [0, 2q) on request: below 2q (mod 2^64 for 64-bit q) and congruent to the oracle's
+            fwd = bool(rng.integers(0, 2))
+            x, w = a[:n].copy(), a[:n].copy()
+            (ref.forward_inplace if fwd else ref.backward_inplace)(w)
+            (gpu.forward_inplace_range_2q if fwd else gpu.backward_inplace_range_2q)(x)
+            if 2 * q < 2**64:
+                assert int(x.max()) < 2 * q, tag
+                assert np.array_equal(x % np.uint64(q), w % np.uint64(q)), tag
+            else:          # policies without lazy outputs return the strict ones
+                assert np.array_equal(x, w), tag
         elif mode == 2 and logn >= 16:   # split transform of one vector
             f = logn % 8 or 8
             shards = int(rng.choice([s for s in (1, 2, 4, 8, 16) if s <= (1 << f) and logn >= f + s.bit_length() - 1 + 4]))
